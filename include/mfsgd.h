@@ -1,0 +1,168 @@
+/*
+ * mfsgd.h -- C-ABI of libmfsgd.so, the MI355X (gfx950) matrix-factorisation
+ * SGD trainer.  This is the drop-in boundary: what a JNI / ctypes / cgo stub
+ * binds.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Reference interface replaced: NONE EXISTS.  /root/reference/README.md:1-2 is
+ * the whole reference repository (a title and a course attribution); it has no
+ * class, no FFI and no operator interface.  The surface below follows
+ * SURVEY.md section 8b, which derives it from BASELINE.json's north_star
+ * ("keeping the Java MatrixFactorizationSGD train()/predict() surface ...
+ * through a thin JNI C-ABI").  Each entry point names the Java method it backs
+ * (matrixfactorizationsgd.java_amd/java/MatrixFactorizationSGD.java).
+ *
+ * Conventions
+ *  - every function returns MFSGD_OK (0) or a negative mfsgd_status;
+ *    the message is available from mfsgd_last_error();
+ *  - no C++ exception and no HIP error crosses this boundary;
+ *  - the caller owns every host array passed in or out; the library copies;
+ *  - the handle owns all device memory; mfsgd_destroy() frees it;
+ *  - a handle is not thread-safe; distinct handles are independent;
+ *  - there is NO CPU fallback: compute entry points return
+ *    MFSGD_ERR_NO_DEVICE when no gfx950 device is usable.  Host-only entry
+ *    points (create, set_ratings = schedule construction, schedule queries)
+ *    work without a GPU.
+ */
+#ifndef MFSGD_H
+#define MFSGD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFSGD_ABI_VERSION 1
+
+typedef enum mfsgd_status {
+    MFSGD_OK = 0,
+    MFSGD_ERR_INVALID_ARG = -1,
+    MFSGD_ERR_NO_DEVICE = -2,   /* no HIP device / wrong architecture          */
+    MFSGD_ERR_HIP = -3,         /* a HIP runtime call failed (see last_error)  */
+    MFSGD_ERR_OOM = -4,         /* host or device allocation failed            */
+    MFSGD_ERR_STATE = -5,       /* call order violated (e.g. train before set) */
+    MFSGD_ERR_UNSUPPORTED = -6, /* e.g. k > MFSGD_MAX_K                        */
+    MFSGD_ERR_SCHEDULE = -7     /* no LDS-feasible schedule could be built     */
+} mfsgd_status;
+
+#define MFSGD_MAX_K 256
+
+typedef struct mfsgd_handle mfsgd_handle;
+
+/* Hyper-parameters and geometry.  Zero in an "auto" field selects the default.
+ * Java: constructor MatrixFactorizationSGD(users, items, k, lr, lambda, seed). */
+typedef struct mfsgd_config {
+    int32_t n_users;      /* U: rows of P held by this handle                       */
+    int32_t n_items;      /* I: rows of Q (global item count)                       */
+    int32_t k;            /* latent dimension, 1..MFSGD_MAX_K                       */
+    float lr;             /* learning rate                                          */
+    float lambda;         /* L2 regularisation, shared by P and Q                   */
+    int32_t device;       /* HIP device ordinal                                     */
+    int32_t blocks;       /* B: user blocks = item tiles per side; 0 = auto         */
+    int32_t waves;        /* W: waves per workgroup (1,2,4,8); 0 = auto             */
+    int32_t n_parts;      /* DSGD: item partitions (= GPUs); 0 or 1 = single device */
+    int32_t host_threads; /* schedule-construction threads; 0 = hardware threads    */
+    int32_t flags;        /* MFSGD_FLAG_*                                           */
+    int32_t reserved[5];  /* must be zero                                           */
+} mfsgd_config;
+
+#define MFSGD_FLAG_NO_GRAPH 1 /* launch rounds eagerly instead of via a hipGraph */
+
+/* What the scheduler built; for tests, bench.py's roofline arithmetic, DESIGN. */
+typedef struct mfsgd_schedule_info {
+    int64_t nnz;          /* ratings in this part                                   */
+    int32_t part;         /* item partition this describes                          */
+    int32_t blocks;       /* B                                                      */
+    int32_t waves;        /* W                                                      */
+    int32_t group_lanes;  /* L: lanes per rating (row bytes / 16)                   */
+    int32_t slots;        /* G = 64 / L ratings per wave step                       */
+    int32_t kp;           /* padded row length in floats (device stride)            */
+    int32_t rounds;       /* kernel launches per epoch (= B)                        */
+    int32_t lds_bytes;    /* dynamic LDS requested per workgroup                    */
+    int64_t total_steps;  /* wave steps over all cells                              */
+    int64_t total_rows;   /* factor rows gathered (and scattered) per epoch         */
+    int64_t max_cell_nnz;
+    int64_t max_cell_rows;
+    int64_t max_cell_steps; /* critical path of the slowest cell (sum over sub-rounds of max wave steps) */
+    int64_t sum_round_steps; /* sum over rounds of the slowest cell's critical path */
+    double build_seconds;
+} mfsgd_schedule_info;
+
+/* ---- lifetime ------------------------------------------------------------- */
+int mfsgd_abi_version(void);
+/* Number of usable gfx950 devices; 0 (and MFSGD_OK) when there are none. */
+int mfsgd_device_count(int32_t* out);
+/* Java: constructor.  Does not touch the GPU. */
+int mfsgd_create(const mfsgd_config* cfg, mfsgd_handle** out);
+/* Java: close(). NULL is allowed. */
+void mfsgd_destroy(mfsgd_handle* h);
+/* Message of the last failure on this handle (h == NULL: of the last failed
+ * mfsgd_create on this thread).  Never NULL; valid until the next call. */
+const char* mfsgd_last_error(const mfsgd_handle* h);
+
+/* ---- ratings -> schedule (host) -------------------------------------------
+ * Java: first half of train(int[] u, int[] i, float[] r, int epochs).
+ * COO triples; 0 <= u < n_users, 0 <= i < n_items.  Buckets the ratings into
+ * B x B (user block, item tile) cells per item partition and packs every cell
+ * into conflict-free wave steps.  Host only; replaces any earlier ratings.   */
+int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const float* r,
+                      int64_t nnz);
+
+/* ---- factors --------------------------------------------------------------
+ * Host layout is dense row-major: P is n_users x k, Q is n_items x k.
+ * init: java.util.Random(seed).nextFloat() * (float)(1/sqrt(k)), P then Q.
+ * With n_parts > 1 only P (and nothing of Q) lives in the handle: Q travels
+ * in caller-owned device blocks (mfsgd_part_* below); pass Q = NULL here.    */
+int mfsgd_init_factors(mfsgd_handle* h, int64_t seed);
+int mfsgd_set_factors(mfsgd_handle* h, const float* P, const float* Q);
+int mfsgd_get_factors(mfsgd_handle* h, float* P, float* Q);
+
+/* ---- the hot path ---------------------------------------------------------
+ * Java: second half of train(...).  Runs `epochs` passes over the schedule on
+ * the device.  If rmse_per_epoch != NULL it receives the RMSE after each epoch
+ * (one extra read-only pass per epoch).  Blocks until the device is idle.    */
+int mfsgd_train(mfsgd_handle* h, int32_t epochs, double* rmse_per_epoch);
+/* RMSE over the stored ratings with the current factors. */
+int mfsgd_rmse(mfsgd_handle* h, double* out);
+/* Java: predict(int u, int i) / predict(int[] u, int[] i). */
+int mfsgd_predict(mfsgd_handle* h, const int32_t* u, const int32_t* i, float* out, int64_t n);
+
+/* Timed variant used by bench.py: runs `epochs` training passes bracketed by
+ * HIP events on the handle's stream and returns the elapsed device time and
+ * the number of sgd-round kernel launches inside it.  No RMSE pass.          */
+int mfsgd_train_timed(mfsgd_handle* h, int32_t epochs, double* elapsed_ms, int64_t* launches);
+
+/* ---- schedule introspection (host) ---------------------------------------- */
+int mfsgd_get_schedule_info(const mfsgd_handle* h, int32_t part, mfsgd_schedule_info* out);
+/* Canonical sequential order of partition `part`: order[j] is the index (into
+ * the arrays given to set_ratings) of the j-th rating; length = info.nnz.
+ * cell_ptr has rounds*blocks+1 entries: cell b of round rd covers
+ * order[cell_ptr[rd*blocks+b] .. cell_ptr[rd*blocks+b+1]).                    */
+int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t* cell_ptr);
+
+/* ---- DSGD building blocks (n_parts > 1) ------------------------------------
+ * Item i belongs to partition i % n_parts and is row i / n_parts of that
+ * partition's Q block.  A Q block is a caller-owned DEVICE buffer of
+ * mfsgd_part_rows() x kp floats (kp from schedule_info), so that the host side
+ * can move it between GPUs (RCCL send/recv) without this library knowing.
+ * `stream` is a hipStream_t (NULL = the handle's own stream).                 */
+int mfsgd_part_rows(const mfsgd_handle* h, int32_t part, int32_t* rows);
+/* Fill a HOST buffer (rows x kp, zero padded) with the initial values the
+ * single-device init would give these items for this seed and this U:
+ * the stream position of Q row i is (U_total + i) * k.                        */
+int mfsgd_part_init_q(const mfsgd_handle* h, int32_t part, int64_t seed, int64_t u_total,
+                      float* q_block_host);
+/* One DSGD sub-epoch: every rating of this handle's users whose item is in
+ * `part`, against q_block_dev.  Asynchronous on `stream`.                     */
+int mfsgd_part_train(mfsgd_handle* h, int32_t part, float* q_block_dev, void* stream);
+/* Sum of squared errors of the same ratings (fp64), synchronous. */
+int mfsgd_part_sse(mfsgd_handle* h, int32_t part, const float* q_block_dev, void* stream,
+                   double* sse);
+/* Seeds P when this handle holds users [u_offset, u_offset + n_users) of a
+ * larger problem: stream position of P row u is (u_offset + u) * k.           */
+int mfsgd_init_p_offset(mfsgd_handle* h, int64_t seed, int64_t u_offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

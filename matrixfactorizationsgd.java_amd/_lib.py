@@ -1,0 +1,106 @@
+"""ctypes binding of include/mfsgd.h -- the stub a reference-side maintainer
+would write (INTEGRATION.md shows the JNI equivalent)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libmfsgd.so")
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("n_users", C.c_int32),
+        ("n_items", C.c_int32),
+        ("k", C.c_int32),
+        ("lr", C.c_float),
+        ("lambda_", C.c_float),
+        ("device", C.c_int32),
+        ("blocks", C.c_int32),
+        ("waves", C.c_int32),
+        ("n_parts", C.c_int32),
+        ("host_threads", C.c_int32),
+        ("flags", C.c_int32),
+        ("reserved", C.c_int32 * 5),
+    ]
+
+
+class ScheduleInfo(C.Structure):
+    _fields_ = [
+        ("nnz", C.c_int64),
+        ("part", C.c_int32),
+        ("blocks", C.c_int32),
+        ("waves", C.c_int32),
+        ("group_lanes", C.c_int32),
+        ("slots", C.c_int32),
+        ("kp", C.c_int32),
+        ("rounds", C.c_int32),
+        ("lds_bytes", C.c_int32),
+        ("total_steps", C.c_int64),
+        ("total_rows", C.c_int64),
+        ("max_cell_nnz", C.c_int64),
+        ("max_cell_rows", C.c_int64),
+        ("max_cell_steps", C.c_int64),
+        ("sum_round_steps", C.c_int64),
+        ("build_seconds", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+FLAG_NO_GRAPH = 1
+
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_H = C.c_void_p
+
+# every symbol include/mfsgd.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "mfsgd_abi_version": (C.c_int, []),
+    "mfsgd_device_count": (C.c_int, [_i32p]),
+    "mfsgd_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
+    "mfsgd_destroy": (None, [_H]),
+    "mfsgd_last_error": (C.c_char_p, [_H]),
+    "mfsgd_set_ratings": (C.c_int, [_H, _i32p, _i32p, _f32p, C.c_int64]),
+    "mfsgd_init_factors": (C.c_int, [_H, C.c_int64]),
+    "mfsgd_set_factors": (C.c_int, [_H, _f32p, _f32p]),
+    "mfsgd_get_factors": (C.c_int, [_H, _f32p, _f32p]),
+    "mfsgd_train": (C.c_int, [_H, C.c_int32, _f64p]),
+    "mfsgd_rmse": (C.c_int, [_H, _f64p]),
+    "mfsgd_predict": (C.c_int, [_H, _i32p, _i32p, _f32p, C.c_int64]),
+    "mfsgd_train_timed": (C.c_int, [_H, C.c_int32, _f64p, _i64p]),
+    "mfsgd_get_schedule_info": (C.c_int, [_H, C.c_int32, C.POINTER(ScheduleInfo)]),
+    "mfsgd_get_order": (C.c_int, [_H, C.c_int32, _i64p, _i64p]),
+    "mfsgd_part_rows": (C.c_int, [_H, C.c_int32, _i32p]),
+    "mfsgd_part_init_q": (C.c_int, [_H, C.c_int32, C.c_int64, C.c_int64, _f32p]),
+    "mfsgd_part_train": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mfsgd_part_sse": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, _f64p]),
+    "mfsgd_init_p_offset": (C.c_int, [_H, C.c_int64, C.c_int64]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Loads libmfsgd.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise OSError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C matrixfactorizationsgd.java_amd/csrc` (there is no CPU fallback)"
+        )
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

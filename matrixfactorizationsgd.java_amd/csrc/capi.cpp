@@ -1,0 +1,677 @@
+// capi.cpp -- the C-ABI of include/mfsgd.h over the HIP kernels.
+//
+// No reference counterpart exists (/root/reference/README.md:1-2 is the whole
+// reference); the surface follows SURVEY.md section 8b.  There is no CPU
+// compute path in this library: every compute entry point needs a gfx950
+// device and fails with MFSGD_ERR_NO_DEVICE otherwise.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/mfsgd.h"
+#include "jrandom.hpp"
+#include "kernels.hpp"
+#include "schedule.hpp"
+
+using namespace mfsgd;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct Part {
+    Schedule sched;
+    int32_t q_rows = 0;  // rows of this partition's Q block
+    bool on_device = false;
+    DevBuf d_cells, d_rows, d_subs, d_entries, d_sse_partial, d_sse_out;
+    // training graphs keyed by the Q block pointer they were captured with
+    std::map<const void*, hipGraphExec_t> graphs;
+};
+
+}  // namespace
+
+struct mfsgd_handle {
+    mfsgd_config cfg{};
+    Geometry geo{};
+    int n_parts = 1;
+    std::vector<Part> parts;
+    bool have_ratings = false;
+    int64_t nnz_total = 0;
+
+    // factors: host staging (kp-padded rows) until the device copy is created
+    enum class Where { None, Host, Device } where = Where::None;
+    std::vector<float> hP, hQ;
+    DevBuf dP, dQ;
+
+    bool device_ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    mutable std::string err;
+};
+
+namespace {
+
+int fail(const mfsgd_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((h), e_ == hipErrorOutOfMemory ? MFSGD_ERR_OOM : MFSGD_ERR_HIP,         \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+int usable_devices(int* count, std::string* why) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        *count = 0;
+        if (why) *why = std::string("no HIP device visible (") + hipGetErrorString(e) + ")";
+        return 0;
+    }
+    *count = n;
+    return 0;
+}
+
+int ensure_device(mfsgd_handle* h) {
+    if (h->device_ready) {
+        HIPCHK(h, hipSetDevice(h->cfg.device));
+        return MFSGD_OK;
+    }
+    int n = 0;
+    std::string why;
+    usable_devices(&n, &why);
+    if (n <= 0) return fail(h, MFSGD_ERR_NO_DEVICE, "libmfsgd has no CPU fallback: " + why);
+    if (h->cfg.device < 0 || h->cfg.device >= n)
+        return fail(h, MFSGD_ERR_NO_DEVICE, "device ordinal " + std::to_string(h->cfg.device) +
+                                                " out of range (" + std::to_string(n) + " visible)");
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, h->cfg.device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(h, MFSGD_ERR_NO_DEVICE,
+                    std::string("device is ") + prop.gcnArchName + "; libmfsgd is built for gfx950 only");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreate(&h->ev0));
+    HIPCHK(h, hipEventCreate(&h->ev1));
+    h->device_ready = true;
+    return MFSGD_OK;
+}
+
+int dev_alloc(mfsgd_handle* h, DevBuf& b, size_t bytes) {
+    if (b.p && b.bytes >= bytes) return MFSGD_OK;
+    b.release();
+    if (bytes == 0) bytes = 16;
+    HIPCHK(h, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return MFSGD_OK;
+}
+
+template <class T>
+int upload(mfsgd_handle* h, DevBuf& b, const std::vector<T>& v) {
+    int rc = dev_alloc(h, b, v.size() * sizeof(T));
+    if (rc) return rc;
+    if (!v.empty()) HIPCHK(h, hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MFSGD_OK;
+}
+
+void drop_graphs(Part& p) {
+    for (auto& kv : p.graphs)
+        if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    p.graphs.clear();
+}
+
+int ensure_part_on_device(mfsgd_handle* h, Part& p) {
+    if (p.on_device) return MFSGD_OK;
+    int rc;
+    if ((rc = upload(h, p.d_cells, p.sched.cells))) return rc;
+    if ((rc = upload(h, p.d_rows, p.sched.rows))) return rc;
+    if ((rc = upload(h, p.d_subs, p.sched.subs))) return rc;
+    if ((rc = upload(h, p.d_entries, p.sched.entries))) return rc;
+    if ((rc = dev_alloc(h, p.d_sse_partial, sizeof(double) * (size_t)p.sched.B * p.sched.B))) return rc;
+    if ((rc = dev_alloc(h, p.d_sse_out, sizeof(double)))) return rc;
+    p.on_device = true;
+    return MFSGD_OK;
+}
+
+// factors host <-> device -------------------------------------------------------
+int factors_to_device(mfsgd_handle* h) {
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    if (h->where == mfsgd_handle::Where::Device) return MFSGD_OK;
+    if (h->where == mfsgd_handle::Where::None)
+        return fail(h, MFSGD_ERR_STATE, "factors not initialised: call mfsgd_init_factors or mfsgd_set_factors");
+    if ((rc = upload(h, h->dP, h->hP))) return rc;
+    if (h->n_parts == 1 && (rc = upload(h, h->dQ, h->hQ))) return rc;
+    h->where = mfsgd_handle::Where::Device;
+    std::vector<float>().swap(h->hP);
+    std::vector<float>().swap(h->hQ);
+    return MFSGD_OK;
+}
+
+CellLaunch make_launch(const mfsgd_handle* h, const Part& p, float* Q) {
+    CellLaunch a{};
+    a.P = static_cast<float*>(h->dP.p);
+    a.Q = Q;
+    a.cells = static_cast<const CellDesc*>(p.d_cells.p);
+    a.rows = static_cast<const uint32_t*>(p.d_rows.p);
+    a.subs = static_cast<const SubDesc*>(p.d_subs.p);
+    a.entries = static_cast<const Entry*>(p.d_entries.p);
+    a.B = p.sched.B;
+    a.rd = 0;
+    a.grid = p.sched.B;
+    a.lds_bytes = p.sched.lds_bytes;
+    a.lr = h->cfg.lr;
+    a.c = 1.0f - h->cfg.lr * h->cfg.lambda;
+    a.sse_partial = static_cast<double*>(p.d_sse_partial.p);
+    return a;
+}
+
+int launch_epoch_eager(mfsgd_handle* h, Part& p, float* Q, hipStream_t st) {
+    CellLaunch a = make_launch(h, p, Q);
+    for (int rd = 0; rd < p.sched.B; ++rd) {
+        a.rd = rd;
+        HIPCHK(h, launch_cell(true, h->geo.L, p.sched.W, a, st));
+    }
+    return MFSGD_OK;
+}
+
+// One epoch of partition p against Q on stream st (asynchronous).
+int launch_epoch(mfsgd_handle* h, Part& p, float* Q, hipStream_t st) {
+    if (p.sched.nnz == 0) return MFSGD_OK;
+    if (h->cfg.flags & MFSGD_FLAG_NO_GRAPH) return launch_epoch_eager(h, p, Q, st);
+    auto it = p.graphs.find(Q);
+    if (it == p.graphs.end()) {
+        // capture the B round launches once; replayed every epoch
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        int rc = launch_epoch_eager(h, p, Q, h->stream);
+        hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        HIPCHK(h, e);
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIPCHK(h, e);
+        if (p.graphs.size() >= 8) drop_graphs(p);
+        it = p.graphs.emplace(Q, exec).first;
+    }
+    HIPCHK(h, hipGraphLaunch(it->second, st));
+    return MFSGD_OK;
+}
+
+int launch_sse(mfsgd_handle* h, Part& p, const float* Q, hipStream_t st) {
+    CellLaunch a = make_launch(h, p, const_cast<float*>(Q));
+    a.grid = p.sched.B * p.sched.B;
+    HIPCHK(h, launch_cell(false, h->geo.L, p.sched.W, a, st));
+    HIPCHK(h, launch_reduce_sse(a.sse_partial, (int64_t)a.grid, static_cast<double*>(p.d_sse_out.p), st));
+    return MFSGD_OK;
+}
+
+int part_sse_sync(mfsgd_handle* h, Part& p, const float* Q, hipStream_t st, double* sse) {
+    if (p.sched.nnz == 0) {
+        *sse = 0.0;
+        return MFSGD_OK;
+    }
+    int rc = launch_sse(h, p, Q, st);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(sse, p.d_sse_out.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return MFSGD_OK;
+}
+
+int prepare_compute(mfsgd_handle* h) {
+    if (!h->have_ratings) return fail(h, MFSGD_ERR_STATE, "no ratings: call mfsgd_set_ratings first");
+    int rc = factors_to_device(h);
+    if (rc) return rc;
+    for (Part& p : h->parts)
+        if ((rc = ensure_part_on_device(h, p))) return rc;
+    return MFSGD_OK;
+}
+
+void fill_rows(JRandom& g, float* dst, int64_t rows, int k, int kp, float scale) {
+    for (int64_t x = 0; x < rows; ++x) {
+        float* row = dst + x * kp;
+        for (int f = 0; f < k; ++f) row[f] = g.nextFloat() * scale;
+        for (int f = k; f < kp; ++f) row[f] = 0.0f;
+    }
+}
+
+}  // namespace
+
+// =============================================================================
+extern "C" {
+
+int mfsgd_abi_version(void) { return MFSGD_ABI_VERSION; }
+
+int mfsgd_device_count(int32_t* out) {
+    if (!out) return MFSGD_ERR_INVALID_ARG;
+    int n = 0;
+    usable_devices(&n, nullptr);
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    *out = ok;
+    return MFSGD_OK;
+}
+
+int mfsgd_create(const mfsgd_config* cfg, mfsgd_handle** out) {
+    if (out) *out = nullptr;
+    if (!cfg || !out) {
+        g_create_error = "mfsgd_create: null argument";
+        return MFSGD_ERR_INVALID_ARG;
+    }
+    auto bad = [&](const char* m, int code = MFSGD_ERR_INVALID_ARG) {
+        g_create_error = std::string("mfsgd_create: ") + m;
+        return code;
+    };
+    if (cfg->n_users < 1 || cfg->n_items < 1) return bad("n_users and n_items must be >= 1");
+    if (cfg->k < 1) return bad("k must be >= 1");
+    if (cfg->k > MFSGD_MAX_K) return bad("k exceeds MFSGD_MAX_K (256)", MFSGD_ERR_UNSUPPORTED);
+    if (!(cfg->lr == cfg->lr) || !(cfg->lambda == cfg->lambda)) return bad("lr / lambda is NaN");
+    if (cfg->blocks < 0 || cfg->waves < 0 || cfg->n_parts < 0 || cfg->device < 0 || cfg->host_threads < 0)
+        return bad("negative geometry field");
+    if (cfg->waves != 0 && cfg->waves != 1 && cfg->waves != 2 && cfg->waves != 4 && cfg->waves != 8)
+        return bad("waves must be 0 (auto), 1, 2, 4 or 8");
+    for (int x = 0; x < 5; ++x)
+        if (cfg->reserved[x] != 0) return bad("reserved fields must be zero");
+    mfsgd_handle* h = new (std::nothrow) mfsgd_handle();
+    if (!h) return bad("out of host memory", MFSGD_ERR_OOM);
+    h->cfg = *cfg;
+    h->geo = geometry_for_k(cfg->k);
+    h->n_parts = cfg->n_parts > 1 ? cfg->n_parts : 1;
+    if (h->n_parts > cfg->n_items) {
+        delete h;
+        return bad("n_parts exceeds n_items");
+    }
+    *out = h;
+    return MFSGD_OK;
+}
+
+void mfsgd_destroy(mfsgd_handle* h) {
+    if (!h) return;
+    if (h->device_ready) {
+        (void)hipSetDevice(h->cfg.device);
+        (void)hipStreamSynchronize(h->stream);
+    }
+    for (Part& p : h->parts) {
+        drop_graphs(p);
+        p.d_cells.release();
+        p.d_rows.release();
+        p.d_subs.release();
+        p.d_entries.release();
+        p.d_sse_partial.release();
+        p.d_sse_out.release();
+    }
+    h->dP.release();
+    h->dQ.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* mfsgd_last_error(const mfsgd_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const float* r, int64_t nnz) {
+    if (!h) return MFSGD_ERR_INVALID_ARG;
+    if (nnz < 0 || (nnz > 0 && (!u || !i || !r))) return fail(h, MFSGD_ERR_INVALID_ARG, "set_ratings: null array or negative nnz");
+    try {
+        // drop what an earlier call built (device copies included)
+        if (h->device_ready) {
+            (void)hipSetDevice(h->cfg.device);
+            (void)hipStreamSynchronize(h->stream);
+        }
+        for (Part& p : h->parts) {
+            drop_graphs(p);
+            p.d_cells.release();
+            p.d_rows.release();
+            p.d_subs.release();
+            p.d_entries.release();
+            p.d_sse_partial.release();
+            p.d_sse_out.release();
+        }
+        h->parts.clear();
+        h->have_ratings = false;
+        for (int64_t j = 0; j < nnz; ++j)
+            if (u[j] < 0 || u[j] >= h->cfg.n_users || i[j] < 0 || i[j] >= h->cfg.n_items)
+                return fail(h, MFSGD_ERR_INVALID_ARG, "set_ratings: rating " + std::to_string(j) + " has (u,i) = (" +
+                                                          std::to_string(u[j]) + "," + std::to_string(i[j]) + ") out of range");
+        const int G = h->n_parts;
+        h->parts.resize((size_t)G);
+        SchedParams prm;
+        prm.U = h->cfg.n_users;
+        prm.k = h->cfg.k;
+        prm.B = h->cfg.blocks;
+        prm.W = h->cfg.waves;
+        prm.threads = h->cfg.host_threads;
+        if (G == 1) {
+            Part& p = h->parts[0];
+            p.q_rows = h->cfg.n_items;
+            prm.I = p.q_rows;
+            std::string err;
+            if (build_schedule_auto(prm, u, i, r, nullptr, nnz, p.sched, err) != 0)
+                return fail(h, MFSGD_ERR_SCHEDULE, err);
+        } else {
+            // item i -> partition i % G, local row i / G
+            std::vector<int64_t> cnt((size_t)G, 0);
+            for (int64_t j = 0; j < nnz; ++j) cnt[(size_t)(i[j] % G)]++;
+            for (int g = 0; g < G; ++g) {
+                std::vector<int32_t> uu, ii;
+                std::vector<float> rr;
+                std::vector<int64_t> orig;
+                uu.reserve((size_t)cnt[(size_t)g]);
+                ii.reserve((size_t)cnt[(size_t)g]);
+                rr.reserve((size_t)cnt[(size_t)g]);
+                orig.reserve((size_t)cnt[(size_t)g]);
+                for (int64_t j = 0; j < nnz; ++j)
+                    if (i[j] % G == g) {
+                        uu.push_back(u[j]);
+                        ii.push_back(i[j] / G);
+                        rr.push_back(r[j]);
+                        orig.push_back(j);
+                    }
+                Part& p = h->parts[(size_t)g];
+                p.q_rows = (h->cfg.n_items - g + G - 1) / G;
+                prm.I = p.q_rows;
+                std::string err;
+                if (build_schedule_auto(prm, uu.data(), ii.data(), rr.data(), orig.data(), (int64_t)uu.size(), p.sched, err) != 0)
+                    return fail(h, MFSGD_ERR_SCHEDULE, "partition " + std::to_string(g) + ": " + err);
+            }
+        }
+        h->nnz_total = nnz;
+        h->have_ratings = true;
+        return MFSGD_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(h, MFSGD_ERR_OOM, "set_ratings: out of host memory");
+    } catch (const std::exception& e) {
+        return fail(h, MFSGD_ERR_INVALID_ARG, std::string("set_ratings: ") + e.what());
+    }
+}
+
+int mfsgd_init_p_offset(mfsgd_handle* h, int64_t seed, int64_t u_offset) {
+    if (!h || u_offset < 0) return fail(h, MFSGD_ERR_INVALID_ARG, "init_p_offset: bad argument");
+    try {
+        const int k = h->cfg.k, kp = h->geo.kp;
+        const float scale = (float)(1.0 / std::sqrt((double)k));
+        if (h->where == mfsgd_handle::Where::Device) {
+            h->dP.release();
+            h->dQ.release();
+        }
+        h->hP.assign((size_t)h->cfg.n_users * kp, 0.0f);
+        JRandom g(seed);
+        g.skip((uint64_t)u_offset * (uint64_t)k);
+        fill_rows(g, h->hP.data(), h->cfg.n_users, k, kp, scale);
+        h->hQ.clear();
+        h->where = mfsgd_handle::Where::Host;
+        return MFSGD_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(h, MFSGD_ERR_OOM, "init_p_offset: out of host memory");
+    }
+}
+
+int mfsgd_init_factors(mfsgd_handle* h, int64_t seed) {
+    if (!h) return MFSGD_ERR_INVALID_ARG;
+    int rc = mfsgd_init_p_offset(h, seed, 0);
+    if (rc) return rc;
+    if (h->n_parts > 1) return MFSGD_OK;  // Q lives in caller-owned blocks
+    try {
+        const int k = h->cfg.k, kp = h->geo.kp;
+        const float scale = (float)(1.0 / std::sqrt((double)k));
+        h->hQ.assign((size_t)h->cfg.n_items * kp, 0.0f);
+        JRandom g(seed);
+        g.skip((uint64_t)h->cfg.n_users * (uint64_t)k);
+        fill_rows(g, h->hQ.data(), h->cfg.n_items, k, kp, scale);
+        return MFSGD_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(h, MFSGD_ERR_OOM, "init_factors: out of host memory");
+    }
+}
+
+int mfsgd_set_factors(mfsgd_handle* h, const float* P, const float* Q) {
+    if (!h || !P) return fail(h, MFSGD_ERR_INVALID_ARG, "set_factors: P is null");
+    if (h->n_parts == 1 && !Q) return fail(h, MFSGD_ERR_INVALID_ARG, "set_factors: Q is null");
+    try {
+        const int k = h->cfg.k, kp = h->geo.kp;
+        if (h->where == mfsgd_handle::Where::Device) {
+            h->dP.release();
+            h->dQ.release();
+        }
+        h->hP.assign((size_t)h->cfg.n_users * kp, 0.0f);
+        for (int64_t x = 0; x < h->cfg.n_users; ++x) std::memcpy(&h->hP[(size_t)x * kp], P + x * k, sizeof(float) * (size_t)k);
+        h->hQ.clear();
+        if (h->n_parts == 1) {
+            h->hQ.assign((size_t)h->cfg.n_items * kp, 0.0f);
+            for (int64_t x = 0; x < h->cfg.n_items; ++x) std::memcpy(&h->hQ[(size_t)x * kp], Q + x * k, sizeof(float) * (size_t)k);
+        }
+        h->where = mfsgd_handle::Where::Host;
+        return MFSGD_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(h, MFSGD_ERR_OOM, "set_factors: out of host memory");
+    }
+}
+
+int mfsgd_get_factors(mfsgd_handle* h, float* P, float* Q) {
+    if (!h) return MFSGD_ERR_INVALID_ARG;
+    if (h->where == mfsgd_handle::Where::None) return fail(h, MFSGD_ERR_STATE, "get_factors: factors not initialised");
+    try {
+        const int k = h->cfg.k, kp = h->geo.kp;
+        const std::vector<float>*sp = &h->hP, *sq = &h->hQ;
+        std::vector<float> tp, tq;
+        if (h->where == mfsgd_handle::Where::Device) {
+            HIPCHK(h, hipSetDevice(h->cfg.device));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (P) {
+                tp.resize((size_t)h->cfg.n_users * kp);
+                HIPCHK(h, hipMemcpy(tp.data(), h->dP.p, tp.size() * sizeof(float), hipMemcpyDeviceToHost));
+            }
+            if (Q && h->n_parts == 1) {
+                tq.resize((size_t)h->cfg.n_items * kp);
+                HIPCHK(h, hipMemcpy(tq.data(), h->dQ.p, tq.size() * sizeof(float), hipMemcpyDeviceToHost));
+            }
+            sp = &tp;
+            sq = &tq;
+        }
+        if (P)
+            for (int64_t x = 0; x < h->cfg.n_users; ++x) std::memcpy(P + x * k, &(*sp)[(size_t)x * kp], sizeof(float) * (size_t)k);
+        if (Q) {
+            if (h->n_parts != 1) return fail(h, MFSGD_ERR_STATE, "get_factors: Q lives in caller-owned blocks when n_parts > 1");
+            for (int64_t x = 0; x < h->cfg.n_items; ++x) std::memcpy(Q + x * k, &(*sq)[(size_t)x * kp], sizeof(float) * (size_t)k);
+        }
+        return MFSGD_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(h, MFSGD_ERR_OOM, "get_factors: out of host memory");
+    }
+}
+
+int mfsgd_train(mfsgd_handle* h, int32_t epochs, double* rmse_per_epoch) {
+    if (!h || epochs < 0) return fail(h, MFSGD_ERR_INVALID_ARG, "train: bad argument");
+    if (h->n_parts != 1) return fail(h, MFSGD_ERR_STATE, "train: handle has n_parts > 1, drive it with mfsgd_part_train");
+    int rc = prepare_compute(h);
+    if (rc) return rc;
+    Part& p = h->parts[0];
+    float* Q = static_cast<float*>(h->dQ.p);
+    for (int e = 0; e < epochs; ++e) {
+        if ((rc = launch_epoch(h, p, Q, h->stream))) return rc;
+        if (rmse_per_epoch) {
+            double sse = 0.0;
+            if ((rc = part_sse_sync(h, p, Q, h->stream, &sse))) return rc;
+            rmse_per_epoch[e] = p.sched.nnz > 0 ? std::sqrt(sse / (double)p.sched.nnz) : 0.0;
+        }
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MFSGD_OK;
+}
+
+int mfsgd_train_timed(mfsgd_handle* h, int32_t epochs, double* elapsed_ms, int64_t* launches) {
+    if (!h || epochs < 0 || !elapsed_ms) return fail(h, MFSGD_ERR_INVALID_ARG, "train_timed: bad argument");
+    if (h->n_parts != 1) return fail(h, MFSGD_ERR_STATE, "train_timed: single-partition handles only");
+    int rc = prepare_compute(h);
+    if (rc) return rc;
+    Part& p = h->parts[0];
+    float* Q = static_cast<float*>(h->dQ.p);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for (int e = 0; e < epochs; ++e)
+        if ((rc = launch_epoch(h, p, Q, h->stream))) return rc;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *elapsed_ms = (double)ms;
+    if (launches) *launches = p.sched.nnz > 0 ? (int64_t)epochs * p.sched.B : 0;
+    return MFSGD_OK;
+}
+
+int mfsgd_rmse(mfsgd_handle* h, double* out) {
+    if (!h || !out) return fail(h, MFSGD_ERR_INVALID_ARG, "rmse: null argument");
+    if (h->n_parts != 1) return fail(h, MFSGD_ERR_STATE, "rmse: handle has n_parts > 1, use mfsgd_part_sse");
+    int rc = prepare_compute(h);
+    if (rc) return rc;
+    Part& p = h->parts[0];
+    double sse = 0.0;
+    if ((rc = part_sse_sync(h, p, static_cast<const float*>(h->dQ.p), h->stream, &sse))) return rc;
+    *out = p.sched.nnz > 0 ? std::sqrt(sse / (double)p.sched.nnz) : 0.0;
+    return MFSGD_OK;
+}
+
+int mfsgd_predict(mfsgd_handle* h, const int32_t* u, const int32_t* i, float* out, int64_t n) {
+    if (!h || n < 0 || (n > 0 && (!u || !i || !out))) return fail(h, MFSGD_ERR_INVALID_ARG, "predict: bad argument");
+    if (h->n_parts != 1) return fail(h, MFSGD_ERR_STATE, "predict: single-partition handles only");
+    for (int64_t j = 0; j < n; ++j)
+        if (u[j] < 0 || u[j] >= h->cfg.n_users || i[j] < 0 || i[j] >= h->cfg.n_items)
+            return fail(h, MFSGD_ERR_INVALID_ARG, "predict: pair " + std::to_string(j) + " out of range");
+    if (n == 0) return MFSGD_OK;
+    int rc = factors_to_device(h);
+    if (rc) return rc;
+    DevBuf du, di, dout;
+    auto cleanup = [&]() {
+        du.release();
+        di.release();
+        dout.release();
+    };
+    rc = dev_alloc(h, du, sizeof(int32_t) * (size_t)n);
+    if (!rc) rc = dev_alloc(h, di, sizeof(int32_t) * (size_t)n);
+    if (!rc) rc = dev_alloc(h, dout, sizeof(float) * (size_t)n);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(du.p, u, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(di.p, i, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess)
+        e = launch_predict(h->geo.L, static_cast<const float*>(h->dP.p), static_cast<const float*>(h->dQ.p),
+                           static_cast<const int32_t*>(du.p), static_cast<const int32_t*>(di.p),
+                           static_cast<float*>(dout.p), n, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(h, MFSGD_ERR_HIP, std::string("predict: ") + hipGetErrorString(e));
+    return MFSGD_OK;
+}
+
+int mfsgd_get_schedule_info(const mfsgd_handle* h, int32_t part, mfsgd_schedule_info* out) {
+    if (!h || !out) return fail(h, MFSGD_ERR_INVALID_ARG, "get_schedule_info: null argument");
+    if (!h->have_ratings) return fail(h, MFSGD_ERR_STATE, "get_schedule_info: no ratings");
+    if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "get_schedule_info: bad partition");
+    const Schedule& s = h->parts[(size_t)part].sched;
+    std::memset(out, 0, sizeof *out);
+    out->nnz = s.nnz;
+    out->part = part;
+    out->blocks = s.B;
+    out->waves = s.W;
+    out->group_lanes = s.geo.L;
+    out->slots = s.geo.G;
+    out->kp = s.geo.kp;
+    out->rounds = s.B;
+    out->lds_bytes = s.lds_bytes;
+    out->total_steps = s.total_steps;
+    out->total_rows = s.total_rows;
+    out->max_cell_nnz = s.max_cell_nnz;
+    out->max_cell_rows = s.max_cell_rows;
+    out->max_cell_steps = s.max_cell_steps;
+    out->sum_round_steps = s.sum_round_steps;
+    out->build_seconds = s.build_seconds;
+    return MFSGD_OK;
+}
+
+int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t* cell_ptr) {
+    if (!h) return MFSGD_ERR_INVALID_ARG;
+    if (!h->have_ratings) return fail(h, MFSGD_ERR_STATE, "get_order: no ratings");
+    if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "get_order: bad partition");
+    const Schedule& s = h->parts[(size_t)part].sched;
+    if (order && !s.order.empty()) std::memcpy(order, s.order.data(), s.order.size() * sizeof(int64_t));
+    if (cell_ptr) std::memcpy(cell_ptr, s.cell_ptr.data(), s.cell_ptr.size() * sizeof(int64_t));
+    return MFSGD_OK;
+}
+
+int mfsgd_part_rows(const mfsgd_handle* h, int32_t part, int32_t* rows) {
+    if (!h || !rows) return fail(h, MFSGD_ERR_INVALID_ARG, "part_rows: null argument");
+    if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_rows: bad partition");
+    *rows = (h->cfg.n_items - part + h->n_parts - 1) / h->n_parts;
+    return MFSGD_OK;
+}
+
+int mfsgd_part_init_q(const mfsgd_handle* h, int32_t part, int64_t seed, int64_t u_total, float* q_block_host) {
+    if (!h || !q_block_host || u_total < 0) return fail(h, MFSGD_ERR_INVALID_ARG, "part_init_q: bad argument");
+    if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_init_q: bad partition");
+    const int k = h->cfg.k, kp = h->geo.kp, G = h->n_parts;
+    const float scale = (float)(1.0 / std::sqrt((double)k));
+    const int32_t rows = (h->cfg.n_items - part + G - 1) / G;
+    JRandom g(seed);
+    g.skip(((uint64_t)u_total + (uint64_t)part) * (uint64_t)k);
+    for (int32_t x = 0; x < rows; ++x) {
+        float* row = q_block_host + (size_t)x * kp;
+        for (int f = 0; f < k; ++f) row[f] = g.nextFloat() * scale;
+        for (int f = k; f < kp; ++f) row[f] = 0.0f;
+        g.skip((uint64_t)(G - 1) * (uint64_t)k);  // next item of this partition is G rows further
+    }
+    return MFSGD_OK;
+}
+
+int mfsgd_part_train(mfsgd_handle* h, int32_t part, float* q_block_dev, void* stream) {
+    if (!h || !q_block_dev) return fail(h, MFSGD_ERR_INVALID_ARG, "part_train: null argument");
+    if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_train: bad partition");
+    int rc = prepare_compute(h);
+    if (rc) return rc;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    return launch_epoch(h, h->parts[(size_t)part], q_block_dev, st);
+}
+
+int mfsgd_part_sse(mfsgd_handle* h, int32_t part, const float* q_block_dev, void* stream, double* sse) {
+    if (!h || !q_block_dev || !sse) return fail(h, MFSGD_ERR_INVALID_ARG, "part_sse: null argument");
+    if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_sse: bad partition");
+    int rc = prepare_compute(h);
+    if (rc) return rc;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    return part_sse_sync(h, h->parts[(size_t)part], q_block_dev, st, sse);
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// kernels.hpp -- host-callable launchers of kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "schedule.hpp"
+
+namespace mfsgd {
+
+struct CellLaunch {
+    float* P;
+    float* Q;
+    const CellDesc* cells;
+    const uint32_t* rows;
+    const SubDesc* subs;
+    const Entry* entries;
+    int B;
+    int rd;          // round (training only)
+    int grid;        // workgroups: B for a training round, B*B for an SSE pass
+    int lds_bytes;   // dynamic LDS per workgroup
+    float lr;
+    float c;         // 1 - lr*lambda
+    double* sse_partial;
+};
+
+// One training round (train = true) or the SSE pass over every cell.
+hipError_t launch_cell(bool train, int L, int W, const CellLaunch& a, hipStream_t st);
+hipError_t launch_reduce_sse(const double* partial, int64_t n, double* out, hipStream_t st);
+hipError_t launch_predict(int L, const float* P, const float* Q, const int32_t* u, const int32_t* i,
+                          float* out, int64_t n, hipStream_t st);
+
+}  // namespace mfsgd

@@ -1,0 +1,509 @@
+// schedule.cpp -- see schedule.hpp.  Host only; no HIP calls.
+#include "schedule.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <queue>
+#include <thread>
+
+namespace mfsgd {
+
+Geometry geometry_for_k(int k) {
+    Geometry g{};
+    g.k = k;
+    int need = (k + 3) / 4, L = 1;
+    while (L < need) L <<= 1;
+    g.L = L;
+    g.G = 64 / L;
+    g.kp = 4 * L;
+    g.rowbytes = 16 * L;
+    return g;
+}
+
+namespace {
+
+// Longest-processing-time-first assignment of rows to `nbins` bins by rating
+// count.  Rows with no rating go to bin 0 (they are never touched).
+// Deterministic: ties broken by row index / bin index.
+void lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>& bin) {
+    const int64_t n = (int64_t)deg.size();
+    bin.assign((size_t)n, 0);
+    std::vector<int32_t> idx;
+    idx.reserve((size_t)n);
+    for (int64_t x = 0; x < n; ++x)
+        if (deg[(size_t)x] > 0) idx.push_back((int32_t)x);
+    std::stable_sort(idx.begin(), idx.end(),
+                     [&](int32_t a, int32_t b) { return deg[(size_t)a] > deg[(size_t)b]; });
+    using Item = std::pair<int64_t, int32_t>;  // (load, bin): smallest load, then smallest bin
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
+    for (int32_t b = 0; b < nbins; ++b) heap.push({0, b});
+    for (int32_t x : idx) {
+        Item t = heap.top();
+        heap.pop();
+        bin[(size_t)x] = t.second;
+        t.first += deg[(size_t)x];
+        heap.push(t);
+    }
+}
+
+struct Rat {
+    uint16_t p, q;  // LDS slots
+    float r;
+    int64_t idx;    // caller-visible rating index
+};
+
+struct CellOut {
+    std::vector<uint32_t> rows;
+    std::vector<Entry> entries;
+    std::vector<SubDesc> subs;
+    std::vector<int64_t> order;
+    uint32_t nu = 0, ni = 0, n_steps = 0;
+    int64_t crit = 0;
+};
+
+struct Scratch {
+    std::vector<int32_t> remdeg;    // ratings left on a row inside the current sub-cell
+    std::vector<int32_t> laststep;  // stamp of the step that selected the row (selection phase)
+    std::vector<int32_t> prevstep;  // stamp of the last EMITTED step that used the row
+    std::vector<int8_t> lastslot;   // lane slot the row had in that step
+    std::vector<uint32_t> us, is;
+    std::vector<Rat> rats;
+    std::vector<int32_t> cand;
+    std::vector<uint64_t> keys;
+};
+
+// Packs the ratings rs[0..n) of one sub-cell into steps of G conflict-free
+// slots.  `t0` is the running step stamp of the cell (unique per step).
+void pack_subcell(const Rat* rs, int n, int G, int nrows, Scratch& sc, int32_t& tstamp,
+                  std::vector<Entry>& entries, std::vector<int64_t>& order, uint32_t& n_steps) {
+    n_steps = 0;
+    if (n == 0) return;
+    for (int j = 0; j < n; ++j) {
+        sc.remdeg[rs[j].p]++;
+        sc.remdeg[rs[j].q]++;
+    }
+    sc.cand.resize((size_t)n);
+    std::iota(sc.cand.begin(), sc.cand.end(), 0);
+    int remaining = n;
+    int taken[64];
+    int slot_of[64];
+    while (remaining > 0) {
+        const int32_t t = ++tstamp;
+        // priority: the rating whose busier row has the most work left goes first
+        sc.keys.resize((size_t)remaining);
+        for (int c = 0; c < remaining; ++c) {
+            const Rat& x = rs[sc.cand[(size_t)c]];
+            const uint32_t a = (uint32_t)sc.remdeg[x.p], b = (uint32_t)sc.remdeg[x.q];
+            const uint64_t hi = a > b ? a : b, lo = a > b ? b : a;
+            // descending by (hi, lo), ascending by position: encode position inverted
+            sc.keys[(size_t)c] = (hi << 44) | (lo << 24) | (uint64_t)(0xFFFFFF - (uint32_t)c);
+        }
+        int ntake = 0;
+        if (remaining <= G) {
+            // common tail case: try them all in position order
+            for (int c = 0; c < remaining && ntake < G; ++c) {
+                const Rat& x = rs[sc.cand[(size_t)c]];
+                if (sc.laststep[x.p] == t || sc.laststep[x.q] == t) continue;
+                sc.laststep[x.p] = t;
+                sc.laststep[x.q] = t;
+                taken[ntake++] = c;
+            }
+        } else {
+            // partial selection of the best candidates: repeatedly pick the max
+            // key among not-yet-conflicting candidates.  remaining is small in
+            // the common case; for big sub-cells sort once per step.
+            static thread_local std::vector<int32_t> ordv;
+            ordv.resize((size_t)remaining);
+            std::iota(ordv.begin(), ordv.end(), 0);
+            const int want = std::min(remaining, 4 * G + 8);
+            if (remaining > want) {
+                std::partial_sort(ordv.begin(), ordv.begin() + want, ordv.end(),
+                                  [&](int32_t a, int32_t b) {
+                                      return sc.keys[(size_t)a] > sc.keys[(size_t)b];
+                                  });
+            } else {
+                std::sort(ordv.begin(), ordv.end(), [&](int32_t a, int32_t b) {
+                    return sc.keys[(size_t)a] > sc.keys[(size_t)b];
+                });
+            }
+            int scanned = 0;
+            for (; scanned < want && ntake < G; ++scanned) {
+                const int c = ordv[(size_t)scanned];
+                const Rat& x = rs[sc.cand[(size_t)c]];
+                if (sc.laststep[x.p] == t || sc.laststep[x.q] == t) continue;
+                sc.laststep[x.p] = t;
+                sc.laststep[x.q] = t;
+                taken[ntake++] = c;
+            }
+            if (ntake < G && want < remaining) {
+                // top candidates conflicted: fall back to a full scan in key order
+                std::sort(ordv.begin() + want, ordv.end(), [&](int32_t a, int32_t b) {
+                    return sc.keys[(size_t)a] > sc.keys[(size_t)b];
+                });
+                for (; scanned < remaining && ntake < G; ++scanned) {
+                    const int c = ordv[(size_t)scanned];
+                    const Rat& x = rs[sc.cand[(size_t)c]];
+                    if (sc.laststep[x.p] == t || sc.laststep[x.q] == t) continue;
+                    sc.laststep[x.p] = t;
+                    sc.laststep[x.q] = t;
+                    taken[ntake++] = c;
+                }
+            }
+        }
+        // lane-slot assignment: keep a row in the slot it had in the previous
+        // step when possible (item first: item chains are the long ones)
+        uint64_t freemask = G >= 64 ? ~0ull : ((1ull << G) - 1);
+        for (int j = 0; j < ntake; ++j) slot_of[j] = -1;
+        for (int j = 0; j < ntake; ++j) {
+            const Rat& x = rs[sc.cand[(size_t)taken[j]]];
+            int pref = -1;
+            if (sc.prevstep[x.q] == t - 1) pref = sc.lastslot[x.q];
+            else if (sc.prevstep[x.p] == t - 1) pref = sc.lastslot[x.p];
+            if (pref >= 0 && (freemask >> pref) & 1) {
+                slot_of[j] = pref;
+                freemask &= ~(1ull << pref);
+            }
+        }
+        for (int j = 0; j < ntake; ++j) {
+            if (slot_of[j] >= 0) continue;
+            const int g = __builtin_ctzll(freemask);
+            slot_of[j] = g;
+            freemask &= ~(1ull << g);
+        }
+        // emit
+        const size_t base = entries.size();
+        entries.resize(base + (size_t)G);
+        for (int g = 0; g < G; ++g) {
+            Entry e;
+            e.slots = (uint32_t)(nrows + 2 * g) | ((uint32_t)(nrows + 2 * g + 1) << 16);
+            e.r = 0.0f;
+            entries[base + (size_t)g] = e;
+        }
+        int64_t ord_tmp[64];
+        for (int g = 0; g < G; ++g) ord_tmp[g] = -1;
+        for (int j = 0; j < ntake; ++j) {
+            const Rat& x = rs[sc.cand[(size_t)taken[j]]];
+            const int g = slot_of[j];
+            Entry e;
+            e.slots = (uint32_t)x.p | ((uint32_t)x.q << 16);
+            e.r = x.r;
+            entries[base + (size_t)g] = e;
+            ord_tmp[g] = x.idx;
+            sc.remdeg[x.p]--;
+            sc.remdeg[x.q]--;
+            sc.prevstep[x.p] = t;
+            sc.prevstep[x.q] = t;
+            sc.lastslot[x.p] = (int8_t)g;
+            sc.lastslot[x.q] = (int8_t)g;
+        }
+        for (int g = 0; g < G; ++g)
+            if (ord_tmp[g] >= 0) order.push_back(ord_tmp[g]);
+        // remove taken candidates (positions in cand), keeping relative order
+        std::sort(taken, taken + ntake);
+        int wpos = taken[0], next = 0;
+        for (int c = taken[0]; c < remaining; ++c) {
+            if (next < ntake && taken[next] == c) {
+                ++next;
+                continue;
+            }
+            sc.cand[(size_t)wpos++] = sc.cand[(size_t)c];
+        }
+        remaining -= ntake;
+        ++n_steps;
+    }
+}
+
+}  // namespace
+
+int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, const float* r,
+                   const int64_t* orig, int64_t n, Schedule& out, std::string& err) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    const Geometry geo = geometry_for_k(prm.k);
+    const int B = prm.B, W = prm.W, G = geo.G;
+    if (B < 1 || W < 1 || W > 8 || prm.k < 1 || geo.L > 64) {
+        err = "build_schedule: bad geometry (B, W or k)";
+        return -1;
+    }
+    if ((int64_t)B * B * W * W > (int64_t)1 << 28) {
+        err = "build_schedule: B*W too large";
+        return -1;
+    }
+    const int32_t U = prm.U, I = prm.I;
+    int nthreads = prm.threads > 0 ? prm.threads : (int)std::thread::hardware_concurrency();
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+
+    // ---- degrees and LPT partition into B*W fine bins -----------------------
+    std::vector<int64_t> degu((size_t)U, 0), degi((size_t)I, 0);
+    for (int64_t j = 0; j < n; ++j) {
+        if (u[j] < 0 || u[j] >= U || i[j] < 0 || i[j] >= I) {
+            err = "set_ratings: index out of range at rating " + std::to_string(j);
+            return -1;
+        }
+        degu[(size_t)u[j]]++;
+        degi[(size_t)i[j]]++;
+    }
+    std::vector<int32_t> ubin, ibin;
+    lpt_assign(degu, B * W, ubin);
+    lpt_assign(degi, B * W, ibin);
+    // fine bin f -> block f % B, sub-group f / B
+
+    // ---- counting sort by (cell, sub-round, wave) ---------------------------
+    const int64_t nb = (int64_t)B * B * W * W;
+    std::vector<int64_t> bptr((size_t)nb + 1, 0);
+    auto bucket_of = [&](int64_t j) -> int64_t {
+        const int32_t fu = ubin[(size_t)u[j]], fi = ibin[(size_t)i[j]];
+        const int ub = fu % B, us = fu / B, it = fi % B, is = fi / B;
+        const int s = (is - us + W) % W;
+        return (((int64_t)ub * B + it) * W + s) * W + us;
+    };
+    std::vector<int64_t> bkt((size_t)n);
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t b = bucket_of(j);
+        bkt[(size_t)j] = b;
+        bptr[(size_t)b + 1]++;
+    }
+    for (int64_t b = 0; b < nb; ++b) bptr[(size_t)b + 1] += bptr[(size_t)b];
+    std::vector<int64_t> sorted((size_t)n);
+    {
+        std::vector<int64_t> cur(bptr.begin(), bptr.end() - 1);
+        for (int64_t j = 0; j < n; ++j) sorted[(size_t)cur[(size_t)bkt[(size_t)j]]++] = j;
+    }
+    bkt.clear();
+    bkt.shrink_to_fit();
+
+    // ---- per-cell packing (parallel over cells) ------------------------------
+    const int64_t ncell = (int64_t)B * B;
+    std::vector<CellOut> co((size_t)ncell);
+    std::atomic<int64_t> next_cell{0};
+    std::atomic<int> failed{0};
+    std::string fail_msg;
+    const int WW = W * W;
+    auto worker = [&]() {
+        Scratch sc;
+        for (;;) {
+            const int64_t c = next_cell.fetch_add(1);
+            if (c >= ncell || failed.load()) break;
+            const int64_t lo = bptr[(size_t)(c * WW)], hi = bptr[(size_t)((c + 1) * WW)];
+            CellOut& o = co[(size_t)c];
+            o.subs.assign((size_t)WW, SubDesc{0, 0});
+            if (hi == lo) continue;
+            const int64_t m = hi - lo;
+            sc.us.resize((size_t)m);
+            sc.is.resize((size_t)m);
+            for (int64_t x = 0; x < m; ++x) {
+                const int64_t j = sorted[(size_t)(lo + x)];
+                sc.us[(size_t)x] = (uint32_t)u[j];
+                sc.is[(size_t)x] = (uint32_t)i[j];
+            }
+            std::vector<uint32_t> uu(sc.us.begin(), sc.us.begin() + m), ii(sc.is.begin(), sc.is.begin() + m);
+            std::sort(uu.begin(), uu.end());
+            uu.erase(std::unique(uu.begin(), uu.end()), uu.end());
+            std::sort(ii.begin(), ii.end());
+            ii.erase(std::unique(ii.begin(), ii.end()), ii.end());
+            const int nu = (int)uu.size(), ni = (int)ii.size(), nrows = nu + ni;
+            if (nrows + 2 * G > 65535) {
+                if (!failed.exchange(1)) fail_msg = "lds: cell touches more than 65535 rows";
+                break;
+            }
+            o.nu = (uint32_t)nu;
+            o.ni = (uint32_t)ni;
+            o.rows.reserve((size_t)nrows);
+            o.rows.insert(o.rows.end(), uu.begin(), uu.end());
+            o.rows.insert(o.rows.end(), ii.begin(), ii.end());
+            sc.rats.resize((size_t)m);
+            for (int64_t x = 0; x < m; ++x) {
+                const int64_t j = sorted[(size_t)(lo + x)];
+                Rat t;
+                t.p = (uint16_t)(std::lower_bound(uu.begin(), uu.end(), (uint32_t)u[j]) - uu.begin());
+                t.q = (uint16_t)(nu + (std::lower_bound(ii.begin(), ii.end(), (uint32_t)i[j]) - ii.begin()));
+                t.r = r[j];
+                t.idx = orig ? orig[j] : j;
+                sc.rats[(size_t)x] = t;
+            }
+            sc.remdeg.assign((size_t)nrows, 0);
+            sc.laststep.assign((size_t)nrows, 0);
+            sc.lastslot.assign((size_t)nrows, (int8_t)-1);
+            sc.prevstep.assign((size_t)nrows, 0);
+            int32_t tstamp = 1;               // step stamps start at 2 so that t-1 never matches 0
+            o.entries.reserve((size_t)(m + m / 2 + G));
+            o.order.reserve((size_t)m);
+            uint32_t stepcur = 0;
+            int64_t crit = 0;
+            for (int s = 0; s < W; ++s) {
+                uint32_t smax = 0;
+                for (int w = 0; w < W; ++w) {
+                    const int64_t sb = c * WW + (int64_t)s * W + w;
+                    const int64_t slo = bptr[(size_t)sb] - lo, shi = bptr[(size_t)sb + 1] - lo;
+                    uint32_t ns = 0;
+                    ++tstamp;  // break stickiness across sub-cells
+                    pack_subcell(sc.rats.data() + slo, (int)(shi - slo), G, nrows, sc, tstamp,
+                                 o.entries, o.order, ns);
+                    o.subs[(size_t)(s * W + w)] = SubDesc{stepcur, ns};
+                    stepcur += ns;
+                    smax = std::max(smax, ns);
+                }
+                crit += smax;
+            }
+            o.n_steps = stepcur;
+            o.crit = crit;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        const int nt = (int)std::min<int64_t>(nthreads, ncell);
+        for (int t = 1; t < nt; ++t) th.emplace_back(worker);
+        worker();
+        for (auto& t : th) t.join();
+    }
+    if (failed.load()) {
+        err = fail_msg;
+        return -1;
+    }
+
+    // ---- concatenate in cell order; canonical order is round-major ----------
+    out = Schedule{};
+    out.geo = geo;
+    out.B = B;
+    out.W = W;
+    out.nnz = n;
+    out.cells.resize((size_t)ncell);
+    out.subs.resize((size_t)(ncell * WW));
+    int64_t tot_rows = 0, tot_steps = 0;
+    int lds_need = 0;
+    for (int64_t c = 0; c < ncell; ++c) {
+        const CellOut& o = co[(size_t)c];
+        if (tot_rows > 0xFFFFFFFFll - (int64_t)o.rows.size() || tot_steps > 0xFFFFFFFFll - o.n_steps) {
+            err = "build_schedule: schedule exceeds 32-bit offsets";
+            return -1;
+        }
+        CellDesc d;
+        d.row_off = (uint32_t)tot_rows;
+        d.ent_off = (uint32_t)tot_steps;
+        d.n_steps = o.n_steps;
+        d.nu = (uint16_t)o.nu;
+        d.ni = (uint16_t)o.ni;
+        out.cells[(size_t)c] = d;
+        for (int x = 0; x < WW; ++x)
+            out.subs[(size_t)(c * WW + x)] = o.subs.empty() ? SubDesc{0, 0} : o.subs[(size_t)x];
+        tot_rows += (int64_t)o.rows.size();
+        tot_steps += o.n_steps;
+        const int64_t need = (int64_t)(o.nu + o.ni + 2 * G) * geo.rowbytes + (int64_t)o.n_steps * G * 8 + WW * 8;
+        if (need > prm.lds_budget) {
+            err = "lds: a cell needs " + std::to_string(need) + " bytes of LDS (budget " +
+                  std::to_string(prm.lds_budget) + "); use more blocks";
+            return -1;
+        }
+        lds_need = std::max<int>(lds_need, (int)need);
+        out.max_cell_nnz = std::max<int64_t>(out.max_cell_nnz, (int64_t)o.order.size());
+        out.max_cell_rows = std::max<int64_t>(out.max_cell_rows, (int64_t)o.rows.size());
+        out.max_cell_steps = std::max<int64_t>(out.max_cell_steps, o.crit);
+    }
+    out.lds_bytes = (lds_need + 15) & ~15;
+    out.total_rows = tot_rows;
+    out.total_steps = tot_steps;
+    out.rows.resize((size_t)tot_rows);
+    out.entries.resize((size_t)(tot_steps * G));
+    {
+        std::atomic<int64_t> nc{0};
+        auto copier = [&]() {
+            for (;;) {
+                const int64_t c = nc.fetch_add(64);
+                if (c >= ncell) break;
+                for (int64_t x = c; x < std::min<int64_t>(c + 64, ncell); ++x) {
+                    const CellOut& o = co[(size_t)x];
+                    const CellDesc& d = out.cells[(size_t)x];
+                    if (!o.rows.empty())
+                        std::memcpy(&out.rows[d.row_off], o.rows.data(), o.rows.size() * sizeof(uint32_t));
+                    if (!o.entries.empty())
+                        std::memcpy(&out.entries[(size_t)d.ent_off * G], o.entries.data(),
+                                    o.entries.size() * sizeof(Entry));
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(copier);
+        copier();
+        for (auto& t : th) t.join();
+    }
+    out.order.resize((size_t)n);
+    out.cell_ptr.assign((size_t)ncell + 1, 0);
+    int64_t pos = 0;
+    for (int rd = 0; rd < B; ++rd) {
+        int64_t worst = 0;
+        for (int b = 0; b < B; ++b) {
+            const int64_t c = (int64_t)b * B + (b + rd) % B;
+            const CellOut& o = co[(size_t)c];
+            out.cell_ptr[(size_t)((int64_t)rd * B + b)] = pos;
+            if (!o.order.empty())
+                std::memcpy(&out.order[(size_t)pos], o.order.data(), o.order.size() * sizeof(int64_t));
+            pos += (int64_t)o.order.size();
+            worst = std::max(worst, o.crit);
+        }
+        out.sum_round_steps += worst;
+    }
+    out.cell_ptr[(size_t)ncell] = pos;
+    if (pos != n) {
+        err = "build_schedule: internal error, packed " + std::to_string(pos) + " of " + std::to_string(n);
+        return -1;
+    }
+    out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    return 0;
+}
+
+int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, const float* r,
+                        const int64_t* orig, int64_t n, Schedule& out, std::string& err) {
+    const Geometry geo = geometry_for_k(prm.k);
+    const int32_t minrows = std::max<int32_t>(1, std::min(prm.U, prm.I));
+    int W = prm.W;
+    if (W <= 0) {
+        W = 4;
+        while (W > 1 && (int64_t)W * 8 > minrows) W >>= 1;
+    }
+    const bool autoB = prm.B <= 0;
+    int B = prm.B;
+    if (autoB) {
+        // rows a cell may hold in LDS, leaving a tenth for step entries
+        const double cap_rows = (double)prm.lds_budget * 0.9 / geo.rowbytes - 2.0 * geo.G;
+        // a cell of m ratings touches at most 2m rows, typically ~1.1m
+        const double target_nnz = std::max(16.0, 0.6 * cap_rows);
+        double best = std::ceil(std::sqrt((double)std::max<int64_t>(n, 1) / target_nnz));
+        int64_t bb = (int64_t)best;
+        if (bb <= prm.n_cu) {
+            bb = (bb + 7) / 8 * 8;
+            if (bb > prm.n_cu) bb = prm.n_cu;
+            // a few more blocks than strictly needed keeps every CU busy
+            if (bb > prm.n_cu * 0.7) bb = prm.n_cu;
+        } else {
+            bb = (bb + prm.n_cu - 1) / prm.n_cu * prm.n_cu;
+        }
+        const int64_t lim = std::max<int64_t>(1, minrows / W);
+        if (bb > lim) bb = lim;
+        if (bb < 1) bb = 1;
+        B = (int)bb;
+    }
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        prm.B = B;
+        prm.W = W;
+        const int rc = build_schedule(prm, u, i, r, orig, n, out, err);
+        if (rc == 0) return 0;
+        if (!autoB || err.compare(0, 4, "lds:") != 0) return rc;
+        int64_t nb = B <= prm.n_cu / 2 ? (int64_t)B * 2 : ((int64_t)B / prm.n_cu + 1) * prm.n_cu;
+        const int64_t lim = std::max<int64_t>(1, minrows / W);
+        if (nb > lim) {
+            if (W > 1) {
+                W >>= 1;
+                continue;
+            }
+            return rc;
+        }
+        B = (int)nb;
+    }
+    return -1;
+}
+
+}  // namespace mfsgd

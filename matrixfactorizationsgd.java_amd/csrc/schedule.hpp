@@ -1,0 +1,96 @@
+// schedule.hpp -- host-side rating bucketing and conflict-free step packing.
+//
+// Product code (part of libmfsgd.so).  No reference counterpart exists
+// (/root/reference/README.md:1-2 is the whole reference); this implements
+// SURVEY.md 2.2 row B4 ("rating bucketing / schedule for coalesced gather")
+// and the blocking half of row B7 (DSGD user x item blocks).
+//
+// Model:
+//   * users are cut into B user blocks, items into B item tiles, both balanced
+//     by rating count (LPT), each further cut into W sub-groups;
+//   * cell (ub, it) holds the ratings of user block ub on item tile it;
+//     round rd of an epoch runs the B cells (b, (b + rd) % B) -- no two of them
+//     share a user or an item, so they run on B workgroups with no ordering;
+//   * inside a cell, sub-round s gives wave w the sub-cell
+//     (user sub-group w, item sub-group (w + s) % W): again disjoint;
+//   * inside a sub-cell the ratings are packed into steps of G slots (G = 64/L
+//     lane groups of one wave); the G ratings of a step share no row.
+// Executing rounds, cells, sub-rounds, waves, steps and slots in index order
+// is the canonical sequential order; any conflict-free parallel execution
+// gives bit-identical factors.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mfsgd {
+
+struct Geometry {
+    int k;         // latent dimension
+    int L;         // lanes per rating: smallest power of two >= ceil(k/4)
+    int G;         // ratings per wave step = 64 / L
+    int kp;        // padded row length in floats = 4 * L
+    int rowbytes;  // 16 * L
+};
+Geometry geometry_for_k(int k);
+
+// Device-facing records (layout shared with kernels.hip).
+struct CellDesc {
+    uint32_t row_off;  // first entry of this cell in rows[]
+    uint32_t ent_off;  // first step of this cell (entries index = step * G + slot)
+    uint32_t n_steps;  // steps over all sub-cells
+    uint16_t nu;       // distinct users  -> LDS slots [0, nu)
+    uint16_t ni;       // distinct items  -> LDS slots [nu, nu + ni)
+};
+static_assert(sizeof(CellDesc) == 16, "CellDesc layout");
+
+struct SubDesc {
+    uint32_t off;  // first step, relative to the cell's first step
+    uint32_t n;    // steps
+};
+
+struct Entry {
+    uint32_t slots;  // user LDS slot | item LDS slot << 16
+    float r;
+};
+
+struct SchedParams {
+    int32_t U = 0, I = 0;   // row counts of P and of this partition's Q block
+    int k = 0;
+    int B = 0;              // 0 = auto
+    int W = 0;              // 0 = auto
+    int lds_budget = 160 * 1024 - 512;
+    int n_cu = 256;
+    int threads = 0;        // 0 = hardware_concurrency
+};
+
+struct Schedule {
+    Geometry geo{};
+    int B = 0, W = 0;
+    int64_t nnz = 0;
+    int lds_bytes = 0;
+    std::vector<CellDesc> cells;    // B*B, index ub*B + it
+    std::vector<uint32_t> rows;     // per cell: nu user rows then ni item rows
+    std::vector<SubDesc> subs;      // (cell*W + s)*W + w
+    std::vector<Entry> entries;     // (cell.ent_off + step)*G + slot
+    std::vector<int64_t> order;     // canonical order -> caller's rating index
+    std::vector<int64_t> cell_ptr;  // B*B+1, round-major: rd*B + b
+    // statistics
+    int64_t total_steps = 0, total_rows = 0;
+    int64_t max_cell_nnz = 0, max_cell_rows = 0, max_cell_steps = 0, sum_round_steps = 0;
+    double build_seconds = 0;
+};
+
+// u/i are row indices into P and into this partition's Q block; orig[j] is the
+// caller-visible index of rating j (nullptr = j itself).
+// Returns 0, or -1 with `err` set (err begins with "lds:" when only the LDS
+// budget was exceeded and a larger B may succeed).
+int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, const float* r,
+                   const int64_t* orig, int64_t n, Schedule& out, std::string& err);
+
+// Picks B and W when they are 0 and retries with more blocks on "lds:" errors.
+int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, const float* r,
+                        const int64_t* orig, int64_t n, Schedule& out, std::string& err);
+
+}  // namespace mfsgd

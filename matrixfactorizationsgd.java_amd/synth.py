@@ -1,0 +1,125 @@
+"""Synthetic rating matrices of the shapes BASELINE.json's configs name.
+
+The reference publishes no data and no generator (/root/reference/README.md:1-2),
+and there is no network for MovieLens/Netflix, so every workload is synthetic:
+
+* ground truth: rank-``k_true`` factors ``P*, Q* ~ U(0,1) * sqrt(12/k_true)``
+  (mean rating 3), ``r = dot(P*[u], Q*[i]) + N(0, noise^2)``;
+* ``dense``: every (u, i) pair once (config 0);
+* ``uniform``: nnz distinct pairs uniformly at random (config 1);
+* ``zm`` (Zipf-Mandelbrot): users and items drawn independently with weight
+  ``1/(rank + q)^s``, pairs de-duplicated, ids randomly permuted so that
+  popularity is not correlated with the index.  The offsets are calibrated so
+  that the heaviest user / item carry the share of ratings they carry in the
+  published MovieLens-20M statistics (heaviest item 67,310 of 20,000,263
+  ratings = 0.34 %, heaviest user 9,254 = 0.046 %, lightest user 20).
+  SURVEY.md section 8d proposed a pure Zipf(s=1, q=0); de-duplicated it
+  saturates -- its 18 heaviest items are rated by EVERY user and its heaviest
+  users rate EVERY item -- which no rating dataset resembles, so the offset
+  form replaces it.  ``zipf_q=0`` reproduces the pure form.
+
+Generator: numpy PCG64 seeded per workload (same stream here and on the GPU
+box: same image, same numpy).
+"""
+import math
+
+import numpy as np
+
+# name -> generator arguments.  BASELINE.json configs[0..4].
+WORKLOADS = {
+    "cfg0_dense100x80": dict(U=100, I=80, nnz=8000, k=8, dist="dense", seed=1),
+    "cfg1_ml100k": dict(U=943, I=1682, nnz=100_000, k=32, dist="uniform", seed=2),
+    "cfg2_ml20m": dict(U=138_493, I=26_744, nnz=20_000_000, k=64, dist="zm", seed=3,
+                       q_user=370.0, q_item=40.0),
+    "cfg3_netflix": dict(U=480_189, I=17_770, nnz=100_000_000, k=128, dist="zm", seed=4,
+                         q_user=800.0, q_item=12.0),
+    "cfg4_powerlaw": dict(U=10_000_000, I=1_000_000, nnz=1_000_000_000, k=256, dist="zm", seed=5,
+                          s_user=1.1, s_item=1.1, q_user=2000.0, q_item=200.0),
+}
+
+
+def zm_weights(n, s, q):
+    w = 1.0 / np.power(np.arange(1, n + 1, dtype=np.float64) + q, s)
+    return w / w.sum()
+
+
+def _draw(rng, cdf, m):
+    x = np.searchsorted(cdf, rng.random(m), side="right")
+    np.minimum(x, cdf.size - 1, out=x)
+    return x
+
+
+def make_pairs(U, I, nnz, dist, rng, s_user=1.0, s_item=1.0, q_user=0.0, q_item=0.0):
+    """Returns (u, i) int32 arrays of nnz distinct pairs in random order."""
+    if dist == "dense":
+        if nnz != U * I:
+            raise ValueError("dense needs nnz == U*I")
+        key = np.arange(U * I, dtype=np.int64)
+    elif dist == "uniform":
+        if nnz > U * I:
+            raise ValueError("nnz exceeds U*I")
+        if U * I <= 50_000_000:
+            key = rng.choice(U * I, size=nnz, replace=False).astype(np.int64)
+        else:
+            key = np.empty(0, np.int64)
+            while key.size < nnz:
+                m = int((nnz - key.size) * 1.1) + 1024
+                cand = rng.integers(0, U, m, dtype=np.int64) * I + rng.integers(0, I, m, dtype=np.int64)
+                key = np.unique(np.concatenate([key, cand]))
+            key = rng.permutation(key)[:nnz]
+    elif dist == "zm":
+        cu = np.cumsum(zm_weights(U, s_user, q_user))
+        ci = np.cumsum(zm_weights(I, s_item, q_item))
+        key = np.empty(0, np.int64)
+        while key.size < nnz:
+            m = int((nnz - key.size) * 1.25) + 1024
+            cand = _draw(rng, cu, m).astype(np.int64) * I + _draw(rng, ci, m)
+            key = np.unique(np.concatenate([key, cand]))
+        key = rng.permutation(key)[:nnz]
+        # popularity rank -> random id
+        pu = rng.permutation(U).astype(np.int64)
+        pi = rng.permutation(I).astype(np.int64)
+        key = pu[key // I] * I + pi[key % I]
+    else:
+        raise ValueError(f"unknown dist {dist!r}")
+    key = rng.permutation(key)
+    return (key // I).astype(np.int32), (key % I).astype(np.int32)
+
+
+def make_ratings(U, I, nnz, k, dist="uniform", seed=0, k_true=16, noise=0.1, **kw):
+    """(u, i, r) for one synthetic workload.  `k` is unused by the data (the truth has
+    rank k_true); it is accepted so WORKLOADS entries can be splatted."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    u, i = make_pairs(U, I, nnz, dist, rng, **kw)
+    scale = math.sqrt(12.0 / k_true)
+    Pt = (rng.random((U, k_true), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    Qt = (rng.random((I, k_true), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    r = np.empty(nnz, np.float32)
+    step = 2_000_000
+    for a in range(0, nnz, step):
+        b = min(a + step, nnz)
+        r[a:b] = np.einsum("nk,nk->n", Pt[u[a:b]], Qt[i[a:b]])
+        r[a:b] += rng.normal(0.0, noise, b - a).astype(np.float32)
+    return u, i, r
+
+
+def workload(name, scale=1.0):
+    """Ratings of a named workload; scale < 1 shrinks U, I and nnz together
+    (for parity tests at sizes the oracle finishes in seconds)."""
+    w = dict(WORKLOADS[name])
+    if scale != 1.0:
+        if w["dist"] == "dense":
+            w["U"] = max(2, int(w["U"] * math.sqrt(scale)))
+            w["I"] = max(2, int(w["I"] * math.sqrt(scale)))
+            w["nnz"] = w["U"] * w["I"]
+        else:
+            w["U"] = max(8, int(w["U"] * scale))
+            w["I"] = max(8, int(w["I"] * scale))
+            w["nnz"] = max(16, min(int(w["nnz"] * scale), w["U"] * w["I"] // 2))
+            for q in ("q_user", "q_item"):
+                if q in w:
+                    w[q] = w[q] * scale
+    k = w["k"]
+    args = {x: w[x] for x in w if x not in ("k",)}
+    u, i, r = make_ratings(k=k, **args)
+    return dict(U=w["U"], I=w["I"], nnz=w["nnz"], k=k, u=u, i=i, r=r, name=name, dist=w["dist"])

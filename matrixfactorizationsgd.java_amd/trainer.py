@@ -1,0 +1,208 @@
+"""Python mirror of the Java surface ``MatrixFactorizationSGD`` (train/predict).
+
+The reference repository contains no source (/root/reference/README.md:1-2), so
+the surface is the one SURVEY.md section 8b derives from BASELINE.json:
+``new MatrixFactorizationSGD(users, items, k, lr, lambda, seed)``,
+``double[] train(int[] u, int[] i, float[] r, int epochs)``,
+``float predict(int u, int i)`` / ``float[] predict(int[] u, int[] i)``,
+``close()``.  Every method is a thin call into the C-ABI (include/mfsgd.h).
+"""
+import ctypes as C
+import zlib
+
+import numpy as np
+
+from . import _lib
+
+
+class MfsgdError(RuntimeError):
+    """A C-ABI call returned a non-zero status (the JNI shim throws
+    RuntimeException in the same place)."""
+
+    def __init__(self, code, message):
+        super().__init__(f"mfsgd error {code}: {message}")
+        self.code = code
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class MatrixFactorizationSGD:
+    def __init__(self, users, items, k, lr, lam, seed, *, device=0, blocks=0, waves=0,
+                 n_parts=0, host_threads=0, flags=0):
+        self._lib = _lib.load_library()
+        self._h = C.c_void_p()
+        self.users, self.items, self.k = int(users), int(items), int(k)
+        self.lr, self.lam, self.seed = float(lr), float(lam), int(seed)
+        cfg = _lib.Config(n_users=self.users, n_items=self.items, k=self.k, lr=self.lr,
+                          lambda_=self.lam, device=device, blocks=blocks, waves=waves,
+                          n_parts=n_parts, host_threads=host_threads, flags=flags)
+        rc = self._lib.mfsgd_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise MfsgdError(rc, self._lib.mfsgd_last_error(None).decode())
+        self.n_parts = max(1, int(n_parts))
+        self._ratings_key = None
+        self._initialised = False
+
+    # -- plumbing ---------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise MfsgdError(rc, self._lib.mfsgd_last_error(self._h).decode())
+
+    def _handle(self):
+        if not self._h:
+            raise MfsgdError(-5, "handle is closed")
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mfsgd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- ratings / factors ------------------------------------------------------
+    def set_ratings(self, u, i, r):
+        u, i, r = _i32(u), _i32(i), _f32(r)
+        if not (u.shape == i.shape == r.shape and u.ndim == 1):
+            raise ValueError("u, i, r must be 1-d arrays of equal length")
+        key = (u.size, zlib.crc32(u.tobytes()), zlib.crc32(i.tobytes()), zlib.crc32(r.tobytes()))
+        if key == self._ratings_key:
+            return
+        self._check(self._lib.mfsgd_set_ratings(self._handle(), _p(u, C.c_int32), _p(i, C.c_int32),
+                                                _p(r, C.c_float), u.size))
+        self._ratings_key = key
+
+    def init_factors(self, seed=None):
+        self._check(self._lib.mfsgd_init_factors(self._handle(), self.seed if seed is None else int(seed)))
+        self._initialised = True
+
+    def set_factors(self, P, Q=None):
+        P = _f32(P)
+        if P.shape != (self.users, self.k):
+            raise ValueError("P must be users x k")
+        qp = None
+        if Q is not None:
+            Q = _f32(Q)
+            if Q.shape != (self.items, self.k):
+                raise ValueError("Q must be items x k")
+            qp = _p(Q, C.c_float)
+        self._check(self._lib.mfsgd_set_factors(self._handle(), _p(P, C.c_float), qp))
+        self._initialised = True
+
+    def get_factors(self):
+        P = np.empty((self.users, self.k), np.float32)
+        if self.n_parts > 1:
+            self._check(self._lib.mfsgd_get_factors(self._handle(), _p(P, C.c_float), None))
+            return P, None
+        Q = np.empty((self.items, self.k), np.float32)
+        self._check(self._lib.mfsgd_get_factors(self._handle(), _p(P, C.c_float), _p(Q, C.c_float)))
+        return P, Q
+
+    # -- the Java surface -------------------------------------------------------
+    def train(self, u, i, r, epochs, *, rmse=True):
+        """Runs `epochs` SGD passes over the ratings; returns the RMSE after each
+        epoch (float64 array), as the Java ``double[] train(...)`` does."""
+        self.set_ratings(u, i, r)
+        if not self._initialised:
+            self.init_factors()
+        return self.fit(epochs, rmse=rmse)
+
+    def fit(self, epochs, *, rmse=True):
+        out = np.zeros(int(epochs), np.float64)
+        self._check(self._lib.mfsgd_train(self._handle(), int(epochs),
+                                          _p(out, C.c_double) if rmse else None))
+        return out if rmse else None
+
+    def train_timed(self, epochs):
+        """(elapsed device milliseconds, kernel launches) for `epochs` passes."""
+        ms = C.c_double()
+        launches = C.c_int64()
+        self._check(self._lib.mfsgd_train_timed(self._handle(), int(epochs), C.byref(ms), C.byref(launches)))
+        return ms.value, launches.value
+
+    def rmse(self):
+        out = C.c_double()
+        self._check(self._lib.mfsgd_rmse(self._handle(), C.byref(out)))
+        return out.value
+
+    def predict(self, u, i):
+        scalar = np.isscalar(u) and np.isscalar(i)
+        uu, ii = _i32(np.atleast_1d(u)), _i32(np.atleast_1d(i))
+        if uu.shape != ii.shape or uu.ndim != 1:
+            raise ValueError("u and i must have the same 1-d shape")
+        out = np.empty(uu.size, np.float32)
+        self._check(self._lib.mfsgd_predict(self._handle(), _p(uu, C.c_int32), _p(ii, C.c_int32),
+                                            _p(out, C.c_float), uu.size))
+        return float(out[0]) if scalar else out
+
+    # -- schedule introspection (tests, bench) -----------------------------------
+    def schedule_info(self, part=0):
+        info = _lib.ScheduleInfo()
+        self._check(self._lib.mfsgd_get_schedule_info(self._handle(), int(part), C.byref(info)))
+        return info.as_dict()
+
+    def order(self, part=0):
+        """Canonical sequential order of a partition and its cell boundaries."""
+        info = self.schedule_info(part)
+        order = np.empty(info["nnz"], np.int64)
+        cell_ptr = np.empty(info["rounds"] * info["blocks"] + 1, np.int64)
+        self._check(self._lib.mfsgd_get_order(self._handle(), int(part), _p(order, C.c_int64),
+                                              _p(cell_ptr, C.c_int64)))
+        return order, cell_ptr
+
+    # -- DSGD building blocks (n_parts > 1); see dsgd.py ---------------------------
+    def part_rows(self, part):
+        rows = C.c_int32()
+        self._check(self._lib.mfsgd_part_rows(self._handle(), int(part), C.byref(rows)))
+        return rows.value
+
+    def part_init_q(self, part, seed, u_total):
+        kp = 4 * self._group_lanes()
+        buf = np.zeros((self.part_rows(part), kp), np.float32)
+        self._check(self._lib.mfsgd_part_init_q(self._handle(), int(part), int(seed), int(u_total),
+                                                _p(buf, C.c_float)))
+        return buf
+
+    def init_p_offset(self, seed, u_offset):
+        self._check(self._lib.mfsgd_init_p_offset(self._handle(), int(seed), int(u_offset)))
+        self._initialised = True
+
+    def part_train(self, part, q_block_ptr, stream_ptr=0):
+        self._check(self._lib.mfsgd_part_train(self._handle(), int(part), C.c_void_p(q_block_ptr),
+                                               C.c_void_p(stream_ptr)))
+
+    def part_sse(self, part, q_block_ptr, stream_ptr=0):
+        out = C.c_double()
+        self._check(self._lib.mfsgd_part_sse(self._handle(), int(part), C.c_void_p(q_block_ptr),
+                                             C.c_void_p(stream_ptr), C.byref(out)))
+        return out.value
+
+    def _group_lanes(self):
+        need, L = (self.k + 3) // 4, 1
+        while L < need:
+            L <<= 1
+        return L
+
+    @property
+    def kp(self):
+        return 4 * self._group_lanes()
