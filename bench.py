@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- rating-updates/sec of the MF-SGD hot path on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one epoch: one pass of the hot path (dot, error, rank-1 update of
+P[u] and Q[i]) over every rating of the workload.  N = 1 runs BASELINE.json's
+configs[2] -- the configuration its metric is quoted on: MovieLens-20M shape
+(138,493 x 26,744, 20M ratings), k = 64, fp32 -- on synthetic data.  N > 1 is
+DSGD (weak scaling): every rank holds the same number of users and ratings as
+the N = 1 run, the item factors are cut into N blocks that rotate between the
+ranks over RCCL send/recv; value = ratings processed by all ranks / max-over-
+ranks time.  Ratings, schedules and factors are resident in HBM before the
+timed region; the timed region contains the training passes only (no RMSE
+pass, no host<->device copies).
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (algorithmic bytes of
+the dominant kernel / its average launch duration vs the 8 TB/s HBM peak) and
+"cpu_baseline" (the oracle's multithreaded CPU path on the host cores, N = 1
+only -- a reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+LR, LAM, SEED = 0.01, 0.05, 3
+
+
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))  # a 1-GPU box gives this job 16 cores
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(w, m, budget_s=12.0):
+    """Times the oracle's multithreaded block-schedule epoch (kind "port": this
+    repository's CPU restatement; the reference has no runnable CPU path) on the
+    same ratings and the same schedule, for about `budget_s` seconds."""
+    from tests.oracle_bind import Oracle
+
+    orc = Oracle()
+    info = m.schedule_info()
+    order, cell_ptr = m.order()
+    threads = host_threads()
+    P, Q = orc.init_factors(w["U"], w["I"], w["k"], SEED)
+    # whole epochs; stop once the budget is used (at least one)
+    t_used, epochs = 0.0, 0
+    while epochs < 1 or (t_used < budget_s and t_used / epochs * (epochs + 1) < budget_s * 1.5):
+        t0 = time.perf_counter()
+        orc.sgd_epoch_mt(P, Q, w["u"], w["i"], w["r"], order, cell_ptr, info["rounds"], info["blocks"], LR, LAM, threads)
+        t_used += time.perf_counter() - t0
+        epochs += 1
+    return {
+        "value": w["nnz"] * epochs / t_used,
+        "unit": "updates/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{epochs} full epoch(s) of the same {w['nnz']} ratings and block schedule, "
+                  f"oracle/mfsgd_oracle.c mfo_sgd_epoch_mt, {t_used:.1f} s",
+    }
+
+
+def read_traffic(k, nnz):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary, if one matches."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("k") == k and t.get("nnz") == nnz:
+            return t.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2_ml20m")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only)")
+    ap.add_argument("--blocks", type=int, default=0)
+    ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+
+    import torch
+
+    import mfsgd_amd
+    from mfsgd_amd import _lib, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libmfsgd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- workload (rank-specific users and ratings; items are shared) -----------
+    t0 = time.time()
+    w = synth.workload(args.workload, args.scale, seed_offset=1000 * rank)
+    if rank == 0:
+        log(f"generated {w['nnz']} ratings ({w['U']} x {w['I']}, {w['dist']}) in {time.time() - t0:.1f} s")
+    k, nnz = w["k"], w["nnz"]
+    flags = _lib.FLAG_NO_GRAPH if args.no_graph else 0
+
+    m = mfsgd_amd.MatrixFactorizationSGD(w["U"], w["I"], k, LR, LAM, SEED, device=local_rank, blocks=args.blocks,
+                                         waves=args.waves, n_parts=world if world > 1 else 0,
+                                         host_threads=host_threads(), flags=flags)
+    t0 = time.time()
+    m.set_ratings(w["u"], w["i"], w["r"])
+    infos = [m.schedule_info(p) for p in range(world)]
+    if rank == 0:
+        i0 = infos[0]
+        log(f"schedule built in {time.time() - t0:.1f} s: B={i0['blocks']} W={i0['waves']} G={i0['slots']} "
+            f"lds={i0['lds_bytes']} steps={sum(i['total_steps'] for i in infos)} rows={sum(i['total_rows'] for i in infos)}")
+
+    launches_per_epoch = sum(i["rounds"] for i in infos if i["nnz"] > 0)
+
+    if world == 1:
+        m.init_factors(SEED)
+        rmse0 = m.rmse()  # also moves everything to the device
+        for _ in range(args.warmup):
+            m.fit(1, rmse=False)
+        torch.cuda.synchronize()
+        t_wall0 = time.perf_counter()
+        dev_ms, launches = m.train_timed(args.steps)
+        torch.cuda.synchronize()
+        wall_s = time.perf_counter() - t_wall0
+        elapsed_s = max(wall_s, dev_ms / 1e3)
+        rmse1 = m.rmse()
+        total_updates = nnz * args.steps
+    else:
+        from mfsgd_amd.dsgd import DSGD, HipBackend, TorchDistRing
+
+        u_total = w["U"] * world
+        m.init_p_offset(SEED, rank * w["U"])
+        ring = TorchDistRing(dist, rank, world)
+        d = DSGD(HipBackend(m, dev), ring, rank, world, w["I"], m.kp, SEED, u_total, nnz)
+        sse0, n0 = ring.sum_f64([d.sse(), float(nnz)], torch, dev)
+        rmse0 = (sse0 / n0) ** 0.5
+        for _ in range(args.warmup):
+            d.epoch()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t_wall0 = time.perf_counter()
+        for _ in range(args.steps):
+            d.epoch()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        wall_s = time.perf_counter() - t_wall0
+        elapsed_s = ring.max_f64(wall_s, torch, dev)
+        dev_ms = elapsed_s * 1e3
+        launches = launches_per_epoch * args.steps
+        sse1, n1 = ring.sum_f64([d.sse(), float(nnz)], torch, dev)
+        rmse1 = (sse1 / n1) ** 0.5
+        total_updates = nnz * world * args.steps
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    value = total_updates / elapsed_s
+    # ---- roofline of the dominant kernel (sgd cell kernel, one launch per round) --
+    # algorithmic bytes per update: 12 (COO triple) + 4 rows x 4k bytes, no reuse credited
+    bytes_per_update = 16 * k + 12
+    avg_launch_s = (dev_ms / 1e3) / max(1, launches)
+    units_per_launch = nnz * args.steps / max(1, launches)  # per rank
+    achieved_gbs = units_per_launch * bytes_per_update / avg_launch_s / 1e9
+    roofline = {
+        "bound": "hbm",
+        "kernel": "mfsgd::cell_kernel<L,W,train> (one launch per round)",
+        "achieved": achieved_gbs,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved_gbs / HBM_PEAK_GBS,
+        "traffic": read_traffic(k, nnz) if world == 1 else None,
+        "bytes_per_update": bytes_per_update,
+        "updates_per_launch": units_per_launch,
+        "avg_launch_us": avg_launch_s * 1e6,
+        "launches": launches,
+    }
+    out = {
+        "metric": "rating-updates/sec",
+        "value": value,
+        "unit": "updates/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed_s * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload} (MovieLens-20M shape, Zipf-Mandelbrot degrees)" if args.workload == "cfg2_ml20m" else args.workload,
+            "users_per_gpu": w["U"], "items": w["I"], "nnz_per_gpu": nnz, "k": k,
+            "lr": LR, "lambda": LAM, "scale": args.scale,
+            "blocks": infos[0]["blocks"], "waves": infos[0]["waves"],
+            "parallelism": "single" if world == 1 else f"dsgd{world}",
+        },
+        "rmse_before": rmse0,
+        "rmse_after": rmse1,
+        "device_ms": dev_ms,
+        "wall_ms": wall_s * 1e3,
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        log("timing the CPU baseline (oracle, multithreaded) ...")
+        out["cpu_baseline"] = cpu_baseline(w, m)
+    m.close()
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

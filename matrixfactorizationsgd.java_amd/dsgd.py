@@ -1,0 +1,137 @@
+"""DSGD over the GPUs of one node: user x item blocks, the item-factor blocks
+rotated between ranks (BASELINE.json north_star).
+
+One process per GPU.  Rank g owns the P rows of its users for the whole run and
+a schedule for each of the G item partitions (item i -> partition i % G, row
+i // G of that partition's Q block).  Sub-epoch s: rank g trains partition
+(g + s) % G against the Q block it currently holds -- the G active (user shard,
+item partition) pairs share no user and no item -- then every rank passes its
+block to rank g-1 and receives rank g+1's (a ring shift: one point-to-point
+message per rank over xGMI, RCCL send/recv through torch.distributed; no
+all-to-all, no data-path all-reduce).  After G sub-epochs every block is home.
+
+The compute backend is an object with part_rows/part_init_q/part_train/part_sse;
+the product backend (HipBackend) drives libmfsgd.so.  Tests inject a CPU
+stand-in to exercise this file's rotation logic under gloo.
+"""
+import numpy as np
+
+
+class HipBackend:
+    """libmfsgd.so on one MI355X; Q blocks are torch CUDA tensors (device memory
+    and streams are torch's: plumbing only)."""
+
+    def __init__(self, trainer, torch_device):
+        import torch
+
+        self.t = trainer
+        self.torch = torch
+        self.device = torch_device
+
+    def new_block(self, rows, kp):
+        return self.torch.zeros((rows, kp), dtype=self.torch.float32, device=self.device)
+
+    def load_block(self, block, host_array):
+        block[: host_array.shape[0]].copy_(self.torch.from_numpy(host_array))
+
+    def block_to_host(self, block):
+        return block.cpu().numpy()
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def part_rows(self, part):
+        return self.t.part_rows(part)
+
+    def part_init_q(self, part, seed, u_total):
+        return self.t.part_init_q(part, seed, u_total)
+
+    def part_train(self, part, block):
+        self.t.part_train(part, block.data_ptr(), self._stream())
+
+    def part_sse(self, part, block):
+        return self.t.part_sse(part, block.data_ptr(), self._stream())
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+class TorchDistRing:
+    """Ring shift over torch.distributed (backend "nccl" = RCCL on ROCm, or gloo on CPU)."""
+
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def shift(self, send_block, recv_block):
+        """send to rank-1, receive from rank+1."""
+        if self.world == 1:
+            recv_block.copy_(send_block)
+            return
+        d = self.dist
+        ops = [d.P2POp(d.isend, send_block, (self.rank - 1) % self.world),
+               d.P2POp(d.irecv, recv_block, (self.rank + 1) % self.world)]
+        for req in d.batch_isend_irecv(ops):
+            req.wait()
+
+    def sum_f64(self, values, torch, device):
+        t = torch.tensor(values, dtype=torch.float64, device=device)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().tolist()
+
+    def max_f64(self, value, torch, device):
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.cpu()[0])
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+
+class DSGD:
+    """The rotation schedule.  `backend` computes, `ring` moves blocks."""
+
+    def __init__(self, backend, ring, rank, world, n_items, kp, seed, u_total, nnz_local):
+        self.b, self.ring, self.rank, self.world = backend, ring, rank, world
+        self.seed, self.u_total, self.nnz_local = seed, u_total, nnz_local
+        self.max_rows = (n_items + world - 1) // world
+        self.kp = kp
+        # two buffers: the block being trained and the landing zone of the next one
+        self.cur = backend.new_block(self.max_rows, kp)
+        self.nxt = backend.new_block(self.max_rows, kp)
+        self.part = rank  # partition currently held
+        backend.load_block(self.cur, backend.part_init_q(self.part, seed, u_total))
+
+    def _rotate(self):
+        self.ring.shift(self.cur, self.nxt)
+        self.cur, self.nxt = self.nxt, self.cur
+        self.part = (self.part + 1) % self.world
+
+    def epoch(self):
+        for _ in range(self.world):
+            self.b.part_train(self.part, self.cur)
+            self._rotate()
+
+    def sse(self):
+        """Sum of squared errors of this rank's ratings (one read-only rotation)."""
+        total = 0.0
+        for _ in range(self.world):
+            total += self.b.part_sse(self.part, self.cur)
+            self._rotate()
+        return total
+
+    def home_block(self):
+        """(partition, host copy of its Q block) -- valid between epochs."""
+        rows = self.b.part_rows(self.part)
+        return self.part, self.b.block_to_host(self.cur)[:rows]
+
+
+def assemble_q(blocks, n_items, k, world):
+    """Rebuilds the dense I x k matrix from {partition: block} (tests)."""
+    Q = np.zeros((n_items, k), np.float32)
+    for part, blk in blocks.items():
+        idx = np.arange(part, n_items, world)
+        Q[idx] = blk[: idx.size, :k]
+    return Q

@@ -103,10 +103,12 @@ def make_ratings(U, I, nnz, k, dist="uniform", seed=0, k_true=16, noise=0.1, **k
     return u, i, r
 
 
-def workload(name, scale=1.0):
+def workload(name, scale=1.0, seed_offset=0):
     """Ratings of a named workload; scale < 1 shrinks U, I and nnz together
-    (for parity tests at sizes the oracle finishes in seconds)."""
+    (for parity tests at sizes the oracle finishes in seconds); seed_offset
+    gives each DSGD rank its own users and ratings."""
     w = dict(WORKLOADS[name])
+    w["seed"] = w["seed"] + seed_offset
     if scale != 1.0:
         if w["dist"] == "dense":
             w["U"] = max(2, int(w["U"] * math.sqrt(scale)))
