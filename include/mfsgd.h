@@ -140,6 +140,12 @@ int mfsgd_get_schedule_info(const mfsgd_handle* h, int32_t part, mfsgd_schedule_
  * order[cell_ptr[rd*blocks+b] .. cell_ptr[rd*blocks+b+1]).                    */
 int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t* cell_ptr);
 
+/* Diagnostic (not part of the Java surface): runs training round `round` once with
+ * phase stamps; out receives blocks x 4 shader-clock values per workgroup:
+ * start, after gather, after the rating steps, after scatter.  It DOES apply
+ * that round's updates.  Single-partition handles only.                        */
+int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint64_t* out);
+
 /* ---- DSGD building blocks (n_parts > 1) ------------------------------------
  * Item i belongs to partition i % n_parts and is row i / n_parts of that
  * partition's Q block.  A Q block is a caller-owned DEVICE buffer of

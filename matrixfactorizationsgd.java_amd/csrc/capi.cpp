@@ -632,6 +632,23 @@ int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t
     return MFSGD_OK;
 }
 
+int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint64_t* out) {
+    if (!h || !out) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_round_stamps: null argument");
+    if (h->n_parts != 1 || part != 0) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_round_stamps: single-partition handles only");
+    int rc = prepare_compute(h);
+    if (rc) return rc;
+    Part& p = h->parts[0];
+    if (round < 0 || round >= p.sched.B) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_round_stamps: bad round");
+    if ((size_t)p.sched.B * 4 * sizeof(uint64_t) > p.d_sse_partial.bytes) return fail(h, MFSGD_ERR_STATE, "debug_round_stamps: buffer too small");
+    CellLaunch a = make_launch(h, p, static_cast<float*>(h->dQ.p));
+    a.rd = round;
+    a.diag = true;
+    HIPCHK(h, launch_cell(true, h->geo.L, p.sched.W, a, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out, p.d_sse_partial.p, (size_t)p.sched.B * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MFSGD_OK;
+}
+
 int mfsgd_part_rows(const mfsgd_handle* h, int32_t part, int32_t* rows) {
     if (!h || !rows) return fail(h, MFSGD_ERR_INVALID_ARG, "part_rows: null argument");
     if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_rows: bad partition");

@@ -68,11 +68,21 @@ __device__ __forceinline__ float4 axpy_row(const float s, const float4 x, const 
     return o;
 }
 
-constexpr int GATHER_UNROLL = 4;
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+__device__ __forceinline__ float4 lds_ld(const unsigned char* base, unsigned off) {
+    return *reinterpret_cast<const float4*>(base + off);
+}
+__device__ __forceinline__ void lds_st(unsigned char* base, unsigned off, const float4 v) {
+    *reinterpret_cast<float4*>(base + off) = v;
+}
 
 // One workgroup = one cell.  TRAIN: round `rd` runs cells (b, (b + rd) % B).
 // !TRAIN: blockIdx.x is the cell index, no writes, sum of squared errors out.
-template <int L, int W, bool TRAIN>
+//
+// LDS image: [rows: nrows x ROWB][2G zero rows][entries: n_steps x G x 8][subs: W*W x 8][row ids: nrows x 4]
+template <int L, int W, bool TRAIN, bool DIAG = false>
 __global__ void __launch_bounds__(64 * W)
 cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __restrict__ cells,
             const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs,
@@ -86,11 +96,13 @@ cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __rest
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane / L;
     const int lig = lane % L;
     const int cell = TRAIN ? (int)blockIdx.x * B + ((int)blockIdx.x + rd) % B : (int)blockIdx.x;
     const CellDesc cd = cells[cell];
+    unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
+    if constexpr (DIAG) stamp0 = __builtin_amdgcn_s_memtime();
     const int nu = cd.nu;
     const int nrows = (int)cd.nu + (int)cd.ni;
     if (nrows == 0) {  // uniform over the workgroup
@@ -100,93 +112,189 @@ cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __rest
     unsigned char* const lrows = smem;
     uint2* const lent = reinterpret_cast<uint2*>(smem + (size_t)(nrows + 2 * G) * ROWB);
     uint2* const lsub = lent + (size_t)cd.n_steps * G;
+    uint32_t* const lids = reinterpret_cast<uint32_t*>(lsub + W * W);
 
-    // ---- gather: touched rows -> LDS ------------------------------------------
+    // ---- stage the cell's schedule: row ids, step entries, sub-cell table ---------
+    // (one global latency for all of it; the row gather below depends on the ids)
     const uint32_t* const crow = rows + cd.row_off;
-    {
-        int s = wave * G + g;
-        for (; s + (GATHER_UNROLL - 1) * W * G < nrows; s += GATHER_UNROLL * W * G) {
-            uint32_t rid[GATHER_UNROLL];
-            float4 v[GATHER_UNROLL];
-#pragma unroll
-            for (int x = 0; x < GATHER_UNROLL; ++x) rid[x] = crow[s + x * W * G];
-#pragma unroll
-            for (int x = 0; x < GATHER_UNROLL; ++x) {
-                const int sx = s + x * W * G;
-                const float* src = (sx < nu ? P : Q) + (size_t)rid[x] * KP + lig * 4;
-                v[x] = *reinterpret_cast<const float4*>(src);
-            }
-#pragma unroll
-            for (int x = 0; x < GATHER_UNROLL; ++x)
-                *reinterpret_cast<float4*>(lrows + (size_t)(s + x * W * G) * ROWB + lig * 16) = v[x];
-        }
-        for (; s < nrows; s += W * G) {
-            const uint32_t rid = crow[s];
-            const float* src = (s < nu ? P : Q) + (size_t)rid * KP + lig * 4;
-            *reinterpret_cast<float4*>(lrows + (size_t)s * ROWB + lig * 16) =
-                *reinterpret_cast<const float4*>(src);
-        }
-    }
-    // idle slots of a step point at these all-zero rows: r = 0 keeps them zero
-    for (int x = tid; x < 2 * G * L; x += NT)
-        *reinterpret_cast<float4*>(lrows + (size_t)nrows * ROWB + (size_t)x * 16) =
-            make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int x = tid; x < nrows; x += NT) lids[x] = crow[x];
     {
         const uint2* gent = reinterpret_cast<const uint2*>(entries) + (size_t)cd.ent_off * G;
         const int ne = (int)cd.n_steps * G;
         for (int x = tid; x < ne; x += NT) lent[x] = gent[x];
         if (tid < W * W) lsub[tid] = reinterpret_cast<const uint2*>(subs)[(size_t)cell * W * W + tid];
     }
+    // idle slots of a step point at these all-zero rows: r = 0 keeps them zero
+    for (int x = tid; x < 2 * G * L; x += NT)
+        lds_st(lrows, (unsigned)(nrows * ROWB + x * 16), make_float4(0.f, 0.f, 0.f, 0.f));
     __syncthreads();
 
+    // ---- gather: touched factor rows -> LDS, straight from memory (LDS-DMA) -------
+    // One wave instruction moves G whole rows (64 lanes x 16 B = G x ROWB contiguous
+    // LDS bytes); the source address is per lane, so it is a row gather.  Every load
+    // of the wave is in flight before the single wait.
+    for (int s0 = wave * G; s0 < nrows; s0 += W * G) {
+        const int sx = s0 + g;
+        if (sx < nrows) {
+            const uint32_t rid = lids[sx];
+            const float* src = (sx < nu ? P : Q) + (size_t)rid * KP + lig * 4;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lrows + (size_t)s0 * ROWB), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (DIAG) stamp1 = __builtin_amdgcn_s_memtime();
+
     // ---- apply the ratings out of LDS ------------------------------------------
+    // Software pipeline: the rows of step t+1 are read before the rows of step t are
+    // written back.  The scheduler guarantees (schedule.cpp, "Eligibility") that a
+    // row read that early was not written in step t, except a q-side row in the same
+    // lane slot, which is flagged and taken from registers instead.
     double acc = 0.0;
     const unsigned laneoff = (unsigned)lig * 16u;
+    // Two register sets (A, B) alternate between "current step" and "next step", so
+    // the loop is unrolled by two and nothing is copied between iterations.
+    struct StepRegs {
+        uint2 en;      // entry: addresses | forward flag, rating
+        unsigned pa, qa;
+        float4 p, q;
+    };
+    auto set_addr = [&](StepRegs& x) {
+        x.pa = ((x.en.x & 0xFFFFu) << 4) + laneoff;
+        x.qa = (__builtin_amdgcn_ubfe(x.en.x, 16, 15) << 4) + laneoff;
+    };
+    // One step: `cur` holds step t (entry, addresses, rows); `nxt.en` holds entry t+1.
+    // Leaves `nxt` complete for step t+1 and cur.en = entry t+2 (read from eptr[e2]).
+    auto step = [&](StepRegs& cur, StepRegs& nxt, const uint2* eptr, const int e2) {
+        const float r = __builtin_bit_cast(float, cur.en.y);
+        set_addr(nxt);
+        const float4 pn = lds_ld(lrows, nxt.pa);
+        const float4 qn = lds_ld(lrows, nxt.qa);
+        cur.en = eptr[e2];
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
+        const float dot = group_allreduce<L>(chunk_dot(cur.p, cur.q));
+        const float err = r - dot;
+        if constexpr (TRAIN) {
+            const float sc = lr * err;
+            const float4 p2 = axpy_row(sc, cur.q, c, cur.p);
+            const float4 q2 = axpy_row(sc, cur.p, c, cur.q);
+            lds_st(lrows, cur.pa, p2);
+            lds_st(lrows, cur.qa, q2);
+            const bool fwd = (int)nxt.en.x < 0;
+            nxt.q.x = fwd ? q2.x : qn.x;
+            nxt.q.y = fwd ? q2.y : qn.y;
+            nxt.q.z = fwd ? q2.z : qn.z;
+            nxt.q.w = fwd ? q2.w : qn.w;
+        } else {
+            acc += (double)err * (double)err;
+            nxt.q = qn;
+        }
+        nxt.p = pn;
+    };
+    // Run step: the slot's q row is resident in `rq` for the whole run (no q load, no
+    // select, no q store); idle slots (flag bit) skip the update.
+    float4 rq;
+    auto run_step = [&](StepRegs& cur, StepRegs& nxt, const uint2* eptr, const int e2) {
+        const float r = __builtin_bit_cast(float, cur.en.y);
+        const bool active = (int)cur.en.x >= 0;
+        nxt.pa = ((nxt.en.x & 0xFFFFu) << 4) + laneoff;
+        const float4 pn = lds_ld(lrows, nxt.pa);
+        cur.en = eptr[e2];
+        const float dot = group_allreduce<L>(chunk_dot(cur.p, rq));
+        const float err = r - dot;
+        if constexpr (TRAIN) {
+            // idle slot: s = 0 and c = 1 leave the resident row bit-identical
+            // (fma(0, p, 1*q) == q) and rewrite zeros to the all-zero p row.
+            const float sc = active ? lr * err : 0.0f;
+            const float ce = active ? c : 1.0f;
+            const float4 p2 = axpy_row(sc, rq, ce, cur.p);
+            rq = axpy_row(sc, cur.p, ce, rq);
+            lds_st(lrows, cur.pa, p2);
+        } else {
+            acc += (double)err * (double)err;  // idle: p row and r are zero, err == 0
+        }
+        nxt.p = pn;
+    };
     for (int s = 0; s < W; ++s) {
         const uint2 sd = lsub[s * W + wave];
-        const uint2* e = lent + (size_t)sd.x * G + g;
-        for (uint32_t t = 0; t < sd.y; ++t, e += G) {
-            const uint2 en = *e;
-            unsigned char* const pa = lrows + (en.x & 0xFFFFu) * (unsigned)ROWB + laneoff;
-            unsigned char* const qa = lrows + (en.x >> 16) * (unsigned)ROWB + laneoff;
-            const float4 p = *reinterpret_cast<const float4*>(pa);
-            const float4 q = *reinterpret_cast<const float4*>(qa);
-            const float dot = group_allreduce<L>(chunk_dot(p, q));
-            const float err = __builtin_bit_cast(float, en.y) - dot;
-            if constexpr (TRAIN) {
-                const float sc = lr * err;
-                *reinterpret_cast<float4*>(pa) = axpy_row(sc, q, c, p);
-                *reinterpret_cast<float4*>(qa) = axpy_row(sc, p, c, q);
-            } else {
-                acc += (double)err * (double)err;
+        const int nall = __builtin_amdgcn_readfirstlane((int)sd.y);
+        const int n = nall & 0xFFFF;   // general steps
+        const int nr = nall >> 16;     // run steps, stored after the general ones
+        // entries of this wave's sub-cell; the host pads every cell with two idle
+        // steps, so reading entries t+1 and t+2 past the end stays inside the image
+        const uint2* ebase = lent + (size_t)__builtin_amdgcn_readfirstlane((int)sd.x) * G + g;
+        if (n > 0) {
+            const uint2* eptr = ebase;
+            StepRegs A, B;
+            A.en = eptr[0];
+            B.en = eptr[G];
+            set_addr(A);
+            A.p = lds_ld(lrows, A.pa);
+            A.q = lds_ld(lrows, A.qa);
+            int t = 0;
+            for (; t + 1 < n; t += 2, eptr += 2 * G) {
+                step(A, B, eptr, 2 * G);
+                step(B, A, eptr, 3 * G);
             }
+            if (t < n) step(A, B, eptr, 2 * G);
+        }
+        if (nr > 0) {
+            const uint2* eptr = ebase + (size_t)n * G;
+            StepRegs A, B;
+            A.en = eptr[0];
+            B.en = eptr[G];
+            // every run entry of a slot carries the slot's item address
+            const unsigned rqa = (__builtin_amdgcn_ubfe(A.en.x, 16, 15) << 4) + laneoff;
+            A.pa = ((A.en.x & 0xFFFFu) << 4) + laneoff;
+            rq = lds_ld(lrows, rqa);
+            A.p = lds_ld(lrows, A.pa);
+            int t = 0;
+            for (; t + 1 < nr; t += 2, eptr += 2 * G) {
+                run_step(A, B, eptr, 2 * G);
+                run_step(B, A, eptr, 3 * G);
+            }
+            if (t < nr) run_step(A, B, eptr, 2 * G);
+            if constexpr (TRAIN) lds_st(lrows, rqa, rq);
         }
         if constexpr (TRAIN) __syncthreads();
     }
 
+    if constexpr (DIAG) stamp2 = __builtin_amdgcn_s_memtime();
     if constexpr (TRAIN) {
         // ---- scatter: LDS -> rows ----------------------------------------------
+        constexpr int UNR = 4;
         int s = wave * G + g;
-        for (; s + (GATHER_UNROLL - 1) * W * G < nrows; s += GATHER_UNROLL * W * G) {
-            uint32_t rid[GATHER_UNROLL];
-            float4 v[GATHER_UNROLL];
+        for (; s + (UNR - 1) * W * G < nrows; s += UNR * W * G) {
+            uint32_t rid[UNR];
+            float4 v[UNR];
 #pragma unroll
-            for (int x = 0; x < GATHER_UNROLL; ++x) {
-                rid[x] = crow[s + x * W * G];
-                v[x] = *reinterpret_cast<const float4*>(lrows + (size_t)(s + x * W * G) * ROWB + lig * 16);
+            for (int x = 0; x < UNR; ++x) {
+                rid[x] = lids[s + x * W * G];
+                v[x] = lds_ld(lrows, (unsigned)((s + x * W * G) * ROWB) + laneoff);
             }
 #pragma unroll
-            for (int x = 0; x < GATHER_UNROLL; ++x) {
+            for (int x = 0; x < UNR; ++x) {
                 const int sx = s + x * W * G;
                 float* dst = (sx < nu ? P : Q) + (size_t)rid[x] * KP + lig * 4;
                 *reinterpret_cast<float4*>(dst) = v[x];
             }
         }
         for (; s < nrows; s += W * G) {
-            const uint32_t rid = crow[s];
+            const uint32_t rid = lids[s];
             float* dst = (s < nu ? P : Q) + (size_t)rid * KP + lig * 4;
-            *reinterpret_cast<float4*>(dst) =
-                *reinterpret_cast<const float4*>(lrows + (size_t)s * ROWB + lig * 16);
+            *reinterpret_cast<float4*>(dst) = lds_ld(lrows, (unsigned)(s * ROWB) + laneoff);
+        }
+        if constexpr (DIAG) {
+            // diagnostic build only: phase stamps of this workgroup (shader clock ticks)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
+            if (tid == 0) {
+                unsigned long long* o = reinterpret_cast<unsigned long long*>(sse_partial) + (size_t)blockIdx.x * 4;
+                o[0] = stamp0;
+                o[1] = stamp1;
+                o[2] = stamp2;
+                o[3] = stamp3;
+            }
         }
     } else {
         // ---- deterministic sum of squared errors --------------------------------
@@ -254,7 +362,13 @@ hipError_t launch_cell_LW(bool train, const CellLaunch& a, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)a.grid), block(64 * W);
-    if (train)
+    if (train && a.diag) {
+        const void* fd = (const void*)cell_kernel<L, W, true, true>;
+        e = hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((cell_kernel<L, W, true, true>), grid, block, (size_t)a.lds_bytes, st, a.P, a.Q,
+                           a.cells, a.rows, a.subs, a.entries, a.B, a.rd, a.lr, a.c, a.sse_partial);
+    } else if (train)
         hipLaunchKernelGGL((cell_kernel<L, W, true>), grid, block, (size_t)a.lds_bytes, st, a.P, a.Q,
                            a.cells, a.rows, a.subs, a.entries, a.B, a.rd, a.lr, a.c, a.sse_partial);
     else

@@ -24,6 +24,13 @@ Geometry geometry_for_k(int k) {
     return g;
 }
 
+// LDS image of a cell: rows | 2G all-zero rows | step entries | sub-cell table | row ids
+int64_t lds_bytes_for(const Geometry& geo, int W, int nrows, int64_t n_steps) {
+    int64_t b = (int64_t)(nrows + 2 * geo.G) * geo.rowbytes + n_steps * geo.G * 8 + (int64_t)W * W * 8 +
+                (int64_t)nrows * 4;
+    return (b + 15) & ~(int64_t)15;
+}
+
 namespace {
 
 // Longest-processing-time-first assignment of rows to `nbins` bins by rating
@@ -74,11 +81,20 @@ struct Scratch {
     std::vector<Rat> rats;
     std::vector<int32_t> cand;
     std::vector<uint64_t> keys;
+    std::vector<std::pair<int32_t, uint16_t>> top;
 };
+
+constexpr int kRunMin = 8;  // shortest item chain worth a register-resident run
 
 // Packs the ratings rs[0..n) of one sub-cell into steps of G conflict-free
 // slots.  `t0` is the running step stamp of the cell (unique per step).
-void pack_subcell(const Rat* rs, int n, int G, int nrows, Scratch& sc, int32_t& tstamp,
+// Entry word: p-side LDS address | q-side LDS address << 16 | forward flag << 31,
+// addresses in 16-byte units (slot * L; at most 160 KiB / 16 = 10240 < 2^15).
+inline uint32_t encode_slots(int pslot, int qslot, bool fwd_q, int Lg) {
+    return (uint32_t)(pslot * Lg) | ((uint32_t)(qslot * Lg) << 16) | (fwd_q ? 0x80000000u : 0u);
+}
+
+void pack_subcell(const Rat* rs, int n, int G, int Lg, int nrows, Scratch& sc, int32_t& tstamp,
                   std::vector<Entry>& entries, std::vector<int64_t>& order, uint32_t& n_steps) {
     n_steps = 0;
     if (n == 0) return;
@@ -102,72 +118,49 @@ void pack_subcell(const Rat* rs, int n, int G, int nrows, Scratch& sc, int32_t& 
             // descending by (hi, lo), ascending by position: encode position inverted
             sc.keys[(size_t)c] = (hi << 44) | (lo << 24) | (uint64_t)(0xFFFFFF - (uint32_t)c);
         }
+        // Eligibility (the kernel prefetches the rows of step t+1 before it stores
+        // the rows of step t -- DESIGN.md section 4):
+        //  * a p-side row used in step t-1 may not be used in step t at all;
+        //  * a q-side row used in step t-1 may be used in step t only in the SAME
+        //    lane slot (the kernel then forwards it in registers).
         int ntake = 0;
-        if (remaining <= G) {
-            // common tail case: try them all in position order
-            for (int c = 0; c < remaining && ntake < G; ++c) {
-                const Rat& x = rs[sc.cand[(size_t)c]];
-                if (sc.laststep[x.p] == t || sc.laststep[x.q] == t) continue;
-                sc.laststep[x.p] = t;
-                sc.laststep[x.q] = t;
-                taken[ntake++] = c;
+        uint64_t slot_taken = 0;
+        auto try_take = [&](int c) {
+            const Rat& x = rs[sc.cand[(size_t)c]];
+            if (sc.laststep[x.p] == t || sc.laststep[x.q] == t) return;
+            if (sc.prevstep[x.p] == t - 1) return;
+            int req = -1;
+            if (sc.prevstep[x.q] == t - 1) {
+                req = sc.lastslot[x.q];
+                if ((slot_taken >> req) & 1) return;
+                slot_taken |= 1ull << req;
             }
+            sc.laststep[x.p] = t;
+            sc.laststep[x.q] = t;
+            slot_of[ntake] = req;
+            taken[ntake++] = c;
+        };
+        if (remaining <= G) {
+            for (int c = 0; c < remaining && ntake < G; ++c) try_take(c);
         } else {
-            // partial selection of the best candidates: repeatedly pick the max
-            // key among not-yet-conflicting candidates.  remaining is small in
-            // the common case; for big sub-cells sort once per step.
             static thread_local std::vector<int32_t> ordv;
             ordv.resize((size_t)remaining);
             std::iota(ordv.begin(), ordv.end(), 0);
             const int want = std::min(remaining, 4 * G + 8);
-            if (remaining > want) {
-                std::partial_sort(ordv.begin(), ordv.begin() + want, ordv.end(),
-                                  [&](int32_t a, int32_t b) {
-                                      return sc.keys[(size_t)a] > sc.keys[(size_t)b];
-                                  });
-            } else {
-                std::sort(ordv.begin(), ordv.end(), [&](int32_t a, int32_t b) {
-                    return sc.keys[(size_t)a] > sc.keys[(size_t)b];
-                });
-            }
+            auto by_key = [&](int32_t x, int32_t y) { return sc.keys[(size_t)x] > sc.keys[(size_t)y]; };
+            if (remaining > want)
+                std::partial_sort(ordv.begin(), ordv.begin() + want, ordv.end(), by_key);
+            else
+                std::sort(ordv.begin(), ordv.end(), by_key);
             int scanned = 0;
-            for (; scanned < want && ntake < G; ++scanned) {
-                const int c = ordv[(size_t)scanned];
-                const Rat& x = rs[sc.cand[(size_t)c]];
-                if (sc.laststep[x.p] == t || sc.laststep[x.q] == t) continue;
-                sc.laststep[x.p] = t;
-                sc.laststep[x.q] = t;
-                taken[ntake++] = c;
-            }
+            for (; scanned < want && ntake < G; ++scanned) try_take(ordv[(size_t)scanned]);
             if (ntake < G && want < remaining) {
-                // top candidates conflicted: fall back to a full scan in key order
-                std::sort(ordv.begin() + want, ordv.end(), [&](int32_t a, int32_t b) {
-                    return sc.keys[(size_t)a] > sc.keys[(size_t)b];
-                });
-                for (; scanned < remaining && ntake < G; ++scanned) {
-                    const int c = ordv[(size_t)scanned];
-                    const Rat& x = rs[sc.cand[(size_t)c]];
-                    if (sc.laststep[x.p] == t || sc.laststep[x.q] == t) continue;
-                    sc.laststep[x.p] = t;
-                    sc.laststep[x.q] = t;
-                    taken[ntake++] = c;
-                }
+                std::sort(ordv.begin() + want, ordv.end(), by_key);
+                for (; scanned < remaining && ntake < G; ++scanned) try_take(ordv[(size_t)scanned]);
             }
         }
-        // lane-slot assignment: keep a row in the slot it had in the previous
-        // step when possible (item first: item chains are the long ones)
-        uint64_t freemask = G >= 64 ? ~0ull : ((1ull << G) - 1);
-        for (int j = 0; j < ntake; ++j) slot_of[j] = -1;
-        for (int j = 0; j < ntake; ++j) {
-            const Rat& x = rs[sc.cand[(size_t)taken[j]]];
-            int pref = -1;
-            if (sc.prevstep[x.q] == t - 1) pref = sc.lastslot[x.q];
-            else if (sc.prevstep[x.p] == t - 1) pref = sc.lastslot[x.p];
-            if (pref >= 0 && (freemask >> pref) & 1) {
-                slot_of[j] = pref;
-                freemask &= ~(1ull << pref);
-            }
-        }
+        // lane slots: forwarded rows keep theirs, the rest fill the free ones
+        uint64_t freemask = (G >= 64 ? ~0ull : ((1ull << G) - 1)) & ~slot_taken;
         for (int j = 0; j < ntake; ++j) {
             if (slot_of[j] >= 0) continue;
             const int g = __builtin_ctzll(freemask);
@@ -179,7 +172,7 @@ void pack_subcell(const Rat* rs, int n, int G, int nrows, Scratch& sc, int32_t& 
         entries.resize(base + (size_t)G);
         for (int g = 0; g < G; ++g) {
             Entry e;
-            e.slots = (uint32_t)(nrows + 2 * g) | ((uint32_t)(nrows + 2 * g + 1) << 16);
+            e.slots = encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, Lg);
             e.r = 0.0f;
             entries[base + (size_t)g] = e;
         }
@@ -189,7 +182,7 @@ void pack_subcell(const Rat* rs, int n, int G, int nrows, Scratch& sc, int32_t& 
             const Rat& x = rs[sc.cand[(size_t)taken[j]]];
             const int g = slot_of[j];
             Entry e;
-            e.slots = (uint32_t)x.p | ((uint32_t)x.q << 16);
+            e.slots = encode_slots(x.p, x.q, sc.prevstep[x.q] == t - 1, Lg);
             e.r = x.r;
             entries[base + (size_t)g] = e;
             ord_tmp[g] = x.idx;
@@ -202,6 +195,8 @@ void pack_subcell(const Rat* rs, int n, int G, int nrows, Scratch& sc, int32_t& 
         }
         for (int g = 0; g < G; ++g)
             if (ord_tmp[g] >= 0) order.push_back(ord_tmp[g]);
+        ++n_steps;
+        if (ntake == 0) continue;  // bubble: every remaining rating waits out the hazard rule
         // remove taken candidates (positions in cand), keeping relative order
         std::sort(taken, taken + ntake);
         int wpos = taken[0], next = 0;
@@ -213,6 +208,77 @@ void pack_subcell(const Rat* rs, int n, int G, int nrows, Scratch& sc, int32_t& 
             sc.cand[(size_t)wpos++] = sc.cand[(size_t)c];
         }
         remaining -= ntake;
+    }
+}
+
+
+// Packs the ratings of up to G "run" items of a sub-cell: item j keeps lane slot j and
+// its row stays in registers for the whole run (kernel: run loop).  Each step takes at
+// most one rating per slot; users are distinct inside a step and never repeat in
+// consecutive steps (their rows are prefetched one step ahead).  Idle slots carry the
+// idle flag (bit 31) and the slot's item address, so the kernel can skip them.
+void pack_run(const Rat* rs, int n, const uint16_t* run_q, int nrun, int G, int Lg, int nrows,
+              Scratch& sc, int32_t& tstamp, std::vector<Entry>& entries,
+              std::vector<int64_t>& order, uint32_t& n_steps) {
+    n_steps = 0;
+    if (n == 0) return;
+    // per-slot queues of rating positions, in input order
+    std::vector<int32_t> qpos[64];
+    for (int j = 0; j < n; ++j) {
+        int slot = -1;
+        for (int g = 0; g < nrun; ++g)
+            if (run_q[g] == rs[j].q) slot = g;
+        qpos[slot].push_back(j);
+    }
+    size_t head[64] = {0};
+    int remaining = n;
+    while (remaining > 0) {
+        const int32_t t = ++tstamp;
+        // longest queue first
+        int ord[64];
+        for (int g = 0; g < nrun; ++g) ord[g] = g;
+        std::stable_sort(ord, ord + nrun, [&](int a, int b) {
+            return qpos[a].size() - head[a] > qpos[b].size() - head[b];
+        });
+        const size_t base = entries.size();
+        entries.resize(base + (size_t)G);
+        for (int g = 0; g < G; ++g) {
+            Entry e;
+            const int qslot = g < nrun ? (int)run_q[g] : nrows + 2 * g + 1;
+            e.slots = encode_slots(nrows + 2 * g, qslot, true, Lg);  // bit 31 = idle in a run step
+            e.r = 0.0f;
+            entries[base + (size_t)g] = e;
+        }
+        int64_t ord_tmp[64];
+        for (int g = 0; g < G; ++g) ord_tmp[g] = -1;
+        for (int oi = 0; oi < nrun; ++oi) {
+            const int g = ord[oi];
+            // first rating of this slot whose user is free now and was not used last step
+            for (size_t x = head[g]; x < qpos[g].size(); ++x) {
+                const int j = qpos[g][x];
+                if (j < 0) continue;
+                const Rat& r = rs[j];
+                if (sc.laststep[r.p] == t || sc.prevstep[r.p] == t - 1) continue;
+                sc.laststep[r.p] = t;
+                Entry e;
+                e.slots = encode_slots(r.p, r.q, false, Lg);
+                e.r = r.r;
+                entries[base + (size_t)g] = e;
+                ord_tmp[g] = r.idx;
+                qpos[g][x] = -1;
+                --remaining;
+                break;
+            }
+            while (head[g] < qpos[g].size() && qpos[g][head[g]] < 0) ++head[g];
+        }
+        for (int g = 0; g < G; ++g)
+            if (ord_tmp[g] >= 0) order.push_back(ord_tmp[g]);
+        // users of this step become "previous step" users
+        for (int g = 0; g < G; ++g) {
+            const uint32_t pa = entries[base + (size_t)g].slots & 0xFFFFu;
+            const int pslot = (int)(pa / (uint32_t)Lg);
+            if (pslot < nrows) sc.prevstep[pslot] = t;
+        }
         ++n_steps;
     }
 }
@@ -306,8 +372,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             std::sort(ii.begin(), ii.end());
             ii.erase(std::unique(ii.begin(), ii.end()), ii.end());
             const int nu = (int)uu.size(), ni = (int)ii.size(), nrows = nu + ni;
-            if (nrows + 2 * G > 65535) {
-                if (!failed.exchange(1)) fail_msg = "lds: cell touches more than 65535 rows";
+            if ((int64_t)(nrows + 2 * G) * geo.L > 32767) {
+                if (!failed.exchange(1)) fail_msg = "lds: cell touches more rows than LDS can address";
                 break;
             }
             o.nu = (uint32_t)nu;
@@ -339,17 +405,62 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 for (int w = 0; w < W; ++w) {
                     const int64_t sb = c * WW + (int64_t)s * W + w;
                     const int64_t slo = bptr[(size_t)sb] - lo, shi = bptr[(size_t)sb + 1] - lo;
-                    uint32_t ns = 0;
+                    uint32_t ns = 0, nr = 0;
+                    const int nsub = (int)(shi - slo);
+                    Rat* sub = sc.rats.data() + slo;
+                    // run items: the (at most G) items whose ratings would dominate the step
+                    // count of this sub-cell; their ratings go last, in run mode
+                    uint16_t run_q[64];
+                    int nrun = 0;
+                    if (nsub >= kRunMin) {
+                        for (int j = 0; j < nsub; ++j) sc.remdeg[sub[j].q]++;
+                        std::vector<std::pair<int32_t, uint16_t>>& top = sc.top;
+                        top.clear();
+                        for (int j = 0; j < nsub; ++j) {
+                            const int32_t d = sc.remdeg[sub[j].q];
+                            if (d >= kRunMin && d * G >= nsub) top.push_back({-d, sub[j].q});
+                        }
+                        for (int j = 0; j < nsub; ++j) sc.remdeg[sub[j].q] = 0;
+                        std::sort(top.begin(), top.end());
+                        top.erase(std::unique(top.begin(), top.end()), top.end());
+                        for (size_t x = 0; x < top.size() && nrun < G; ++x) run_q[nrun++] = top[x].second;
+                    }
+                    int ngen = nsub;
+                    if (nrun > 0) {
+                        // stable partition: general ratings first, run ratings after
+                        auto is_run = [&](const Rat& x) {
+                            for (int g = 0; g < nrun; ++g)
+                                if (run_q[g] == x.q) return true;
+                            return false;
+                        };
+                        ngen = (int)(std::stable_partition(sub, sub + nsub, [&](const Rat& x) { return !is_run(x); }) - sub);
+                    }
                     ++tstamp;  // break stickiness across sub-cells
-                    pack_subcell(sc.rats.data() + slo, (int)(shi - slo), G, nrows, sc, tstamp,
-                                 o.entries, o.order, ns);
-                    o.subs[(size_t)(s * W + w)] = SubDesc{stepcur, ns};
-                    stepcur += ns;
-                    smax = std::max(smax, ns);
+                    pack_subcell(sub, ngen, G, geo.L, nrows, sc, tstamp, o.entries, o.order, ns);
+                    if (nrun > 0) {
+                        ++tstamp;  // the run starts with fresh loads: no hazard against the last general step
+                        pack_run(sub + ngen, nsub - ngen, run_q, nrun, G, geo.L, nrows, sc, tstamp, o.entries,
+                                 o.order, nr);
+                    }
+                    if (ns > 0xFFFF || nr > 0xFFFF) {
+                        if (!failed.exchange(1)) fail_msg = "lds: sub-cell has more than 65535 steps";
+                        break;
+                    }
+                    o.subs[(size_t)(s * W + w)] = SubDesc{stepcur, ns | (nr << 16)};
+                    stepcur += ns + nr;
+                    smax = std::max(smax, ns + nr);
                 }
                 crit += smax;
             }
-            o.n_steps = stepcur;
+            // two trailing idle steps: the kernel reads entries t+1 and t+2 ahead
+            for (int pad = 0; pad < 2; ++pad)
+                for (int g = 0; g < G; ++g) {
+                    Entry e;
+                    e.slots = encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, geo.L);
+                    e.r = 0.0f;
+                    o.entries.push_back(e);
+                }
+            o.n_steps = stepcur + 2;
             o.crit = crit;
         }
     };
@@ -392,7 +503,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             out.subs[(size_t)(c * WW + x)] = o.subs.empty() ? SubDesc{0, 0} : o.subs[(size_t)x];
         tot_rows += (int64_t)o.rows.size();
         tot_steps += o.n_steps;
-        const int64_t need = (int64_t)(o.nu + o.ni + 2 * G) * geo.rowbytes + (int64_t)o.n_steps * G * 8 + WW * 8;
+        const int64_t need = lds_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps);
         if (need > prm.lds_budget) {
             err = "lds: a cell needs " + std::to_string(need) + " bytes of LDS (budget " +
                   std::to_string(prm.lds_budget) + "); use more blocks";

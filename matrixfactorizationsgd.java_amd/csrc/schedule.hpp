@@ -34,6 +34,7 @@ struct Geometry {
     int rowbytes;  // 16 * L
 };
 Geometry geometry_for_k(int k);
+int64_t lds_bytes_for(const Geometry& geo, int W, int nrows, int64_t n_steps);
 
 // Device-facing records (layout shared with kernels.hip).
 struct CellDesc {
@@ -47,11 +48,14 @@ static_assert(sizeof(CellDesc) == 16, "CellDesc layout");
 
 struct SubDesc {
     uint32_t off;  // first step, relative to the cell's first step
-    uint32_t n;    // steps
+    uint32_t n;    // general steps | run steps << 16 (run steps follow the general ones)
 };
 
 struct Entry {
-    uint32_t slots;  // user LDS slot | item LDS slot << 16
+    // p-side LDS address | q-side LDS address << 16 | flag << 31; addresses in 16-byte
+    // units.  General step: flag = forward, this slot's q row is the one it updated in the
+    // previous step (take it from registers, not from LDS).  Run step: flag = idle slot.
+    uint32_t slots;
     float r;
 };
 

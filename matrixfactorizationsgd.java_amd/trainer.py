@@ -170,6 +170,13 @@ class MatrixFactorizationSGD:
                                               _p(cell_ptr, C.c_int64)))
         return order, cell_ptr
 
+    def debug_round_stamps(self, rnd):
+        """[blocks, 4] shader-clock stamps of one training round (diagnostic)."""
+        info = self.schedule_info()
+        out = np.zeros((info["blocks"], 4), np.uint64)
+        self._check(self._lib.mfsgd_debug_round_stamps(self._handle(), 0, int(rnd), _p(out, C.c_uint64)))
+        return out
+
     # -- DSGD building blocks (n_parts > 1); see dsgd.py ---------------------------
     def part_rows(self, part):
         rows = C.c_int32()
