@@ -140,6 +140,16 @@ int mfsgd_get_schedule_info(const mfsgd_handle* h, int32_t part, mfsgd_schedule_
  * order[cell_ptr[rd*blocks+b] .. cell_ptr[rd*blocks+b+1]).                    */
 int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t* cell_ptr);
 
+/* Diagnostic (not part of the Java surface): the device-facing schedule arrays of a
+ * partition, so that tests can replay the kernel's exact LDS access order on the CPU.
+ * cells: n_cells x 4 words {row_off, ent_off, n_steps, nu | ni << 16};
+ * subs: n_subs x 2 words {off, general steps | run steps << 16};
+ * entries: n_entries x 2 words {p addr | q addr << 16 | flag << 31 (16-byte units), rating bits}. */
+int mfsgd_debug_schedule_sizes(const mfsgd_handle* h, int32_t part, int64_t* n_cells, int64_t* n_rows,
+                               int64_t* n_subs, int64_t* n_entries);
+int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cells, uint32_t* rows,
+                             uint32_t* subs, uint32_t* entries);
+
 /* Diagnostic (not part of the Java surface): runs training round `round` once with
  * phase stamps; out receives blocks x 4 shader-clock values per workgroup:
  * start, after gather, after the rating steps, after scatter.  It DOES apply
@@ -151,7 +161,9 @@ int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint6
  * partition's Q block.  A Q block is a caller-owned DEVICE buffer of
  * mfsgd_part_rows() x kp floats (kp from schedule_info), so that the host side
  * can move it between GPUs (RCCL send/recv) without this library knowing.
- * `stream` is a hipStream_t (NULL = the handle's own stream).                 */
+ * `stream` is the hipStream_t the caller orders its use of the block on; it is
+ * used as given (NULL = HIP's null stream, which is what torch's default stream
+ * is), never replaced by a private stream.                                     */
 int mfsgd_part_rows(const mfsgd_handle* h, int32_t part, int32_t* rows);
 /* Fill a HOST buffer (rows x kp, zero padded) with the initial values the
  * single-device init would give these items for this seed and this U:

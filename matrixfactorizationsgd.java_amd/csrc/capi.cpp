@@ -632,6 +632,32 @@ int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t
     return MFSGD_OK;
 }
 
+int mfsgd_debug_schedule_sizes(const mfsgd_handle* h, int32_t part, int64_t* n_cells, int64_t* n_rows,
+                               int64_t* n_subs, int64_t* n_entries) {
+    if (!h || !n_cells || !n_rows || !n_subs || !n_entries) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_schedule_sizes: null argument");
+    if (!h->have_ratings) return fail(h, MFSGD_ERR_STATE, "debug_schedule_sizes: no ratings");
+    if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_schedule_sizes: bad partition");
+    const Schedule& s = h->parts[(size_t)part].sched;
+    *n_cells = (int64_t)s.cells.size();
+    *n_rows = (int64_t)s.rows.size();
+    *n_subs = (int64_t)s.subs.size();
+    *n_entries = (int64_t)s.entries.size();
+    return MFSGD_OK;
+}
+
+int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cells, uint32_t* rows, uint32_t* subs,
+                             uint32_t* entries) {
+    if (!h) return MFSGD_ERR_INVALID_ARG;
+    if (!h->have_ratings) return fail(h, MFSGD_ERR_STATE, "debug_get_schedule: no ratings");
+    if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_get_schedule: bad partition");
+    const Schedule& s = h->parts[(size_t)part].sched;
+    if (cells && !s.cells.empty()) std::memcpy(cells, s.cells.data(), s.cells.size() * sizeof(CellDesc));
+    if (rows && !s.rows.empty()) std::memcpy(rows, s.rows.data(), s.rows.size() * sizeof(uint32_t));
+    if (subs && !s.subs.empty()) std::memcpy(subs, s.subs.data(), s.subs.size() * sizeof(SubDesc));
+    if (entries && !s.entries.empty()) std::memcpy(entries, s.entries.data(), s.entries.size() * sizeof(Entry));
+    return MFSGD_OK;
+}
+
 int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint64_t* out) {
     if (!h || !out) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_round_stamps: null argument");
     if (h->n_parts != 1 || part != 0) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_round_stamps: single-partition handles only");
@@ -678,8 +704,8 @@ int mfsgd_part_train(mfsgd_handle* h, int32_t part, float* q_block_dev, void* st
     if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_train: bad partition");
     int rc = prepare_compute(h);
     if (rc) return rc;
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
-    return launch_epoch(h, h->parts[(size_t)part], q_block_dev, st);
+    // the caller owns the Q block, so the caller names the stream (NULL = HIP's null stream)
+    return launch_epoch(h, h->parts[(size_t)part], q_block_dev, static_cast<hipStream_t>(stream));
 }
 
 int mfsgd_part_sse(mfsgd_handle* h, int32_t part, const float* q_block_dev, void* stream, double* sse) {
@@ -687,8 +713,7 @@ int mfsgd_part_sse(mfsgd_handle* h, int32_t part, const float* q_block_dev, void
     if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_sse: bad partition");
     int rc = prepare_compute(h);
     if (rc) return rc;
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
-    return part_sse_sync(h, h->parts[(size_t)part], q_block_dev, st, sse);
+    return part_sse_sync(h, h->parts[(size_t)part], q_block_dev, static_cast<hipStream_t>(stream), sse);
 }
 
 }  // extern "C"

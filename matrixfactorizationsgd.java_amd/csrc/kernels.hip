@@ -15,7 +15,7 @@
 // contraction).
 //
 // Arithmetic is the contract of DESIGN.md section 3 and must stay bit-for-bit
-// what oracle/mfsgd_oracle.c computes: build with -ffp-contract=off.
+// what the CPU checker under oracle/ computes: build with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

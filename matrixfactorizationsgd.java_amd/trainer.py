@@ -170,6 +170,19 @@ class MatrixFactorizationSGD:
                                               _p(cell_ptr, C.c_int64)))
         return order, cell_ptr
 
+    def debug_schedule(self, part=0):
+        """Device-facing schedule arrays (cells, rows, subs, entries) as uint32 arrays."""
+        n = [C.c_int64() for _ in range(4)]
+        self._check(self._lib.mfsgd_debug_schedule_sizes(self._handle(), int(part), *[C.byref(x) for x in n]))
+        cells = np.zeros((n[0].value, 4), np.uint32)
+        rows = np.zeros(n[1].value, np.uint32)
+        subs = np.zeros((n[2].value, 2), np.uint32)
+        entries = np.zeros((n[3].value, 2), np.uint32)
+        self._check(self._lib.mfsgd_debug_get_schedule(self._handle(), int(part), _p(cells, C.c_uint32),
+                                                       _p(rows, C.c_uint32), _p(subs, C.c_uint32),
+                                                       _p(entries, C.c_uint32)))
+        return cells, rows, subs, entries
+
     def debug_round_stamps(self, rnd):
         """[blocks, 4] shader-clock stamps of one training round (diagnostic)."""
         info = self.schedule_info()

@@ -1,0 +1,79 @@
+"""Shared pieces of the DSGD tests: per-rank workloads, the sequential
+definition of one DSGD epoch, and a CPU stand-in for HipBackend (oracle
+arithmetic on the PRODUCT's schedules) used to exercise dsgd.py under gloo."""
+import numpy as np
+
+LR, LAM, SEED = 0.01, 0.05, 21
+
+
+def rank_workload(rank, U_local, I, nnz, seed=100):
+    rng = np.random.default_rng(seed + rank)
+    key = rng.choice(U_local * I, nnz, replace=False)
+    u = (key // I).astype(np.int32)
+    i = (key % I).astype(np.int32)
+    r = (rng.random(nnz) * 4 + 1).astype(np.float32)
+    return u, i, r
+
+
+def sequential_dsgd(oracle, trainers, data, U_local, I, k, G, epochs):
+    """One process, no communication: sub-epoch s, rank g trains partition (g+s)%G.
+    Within a sub-epoch the G (rank, partition) pairs are disjoint, so any order works."""
+    P, Q = oracle.init_factors(U_local * G, I, k, SEED)
+    sse = []
+    for _ in range(epochs):
+        for s in range(G):
+            for g in range(G):
+                part = (g + s) % G
+                u, i, r = data[g]
+                order, _ = trainers[g].order(part)
+                oracle.sgd_pass_ordered(P, Q, u + g * U_local, i, r, order, LR, LAM)
+        tot = 0.0
+        for g in range(G):
+            u, i, r = data[g]
+            tot += oracle.sse(P, Q, u + g * U_local, i, r)
+        sse.append(tot)
+    return P, Q, sse
+
+
+class OracleBackend:
+    """CPU stand-in for dsgd.HipBackend (tests only)."""
+
+    def __init__(self, torch, oracle, trainer, u, i, r, k, G):
+        self.torch, self.o, self.t = torch, oracle, trainer
+        self.u, self.i, self.r, self.k, self.G = u, i, r, k, G
+        self.P, _ = trainer.get_factors()
+
+    def new_block(self, rows, kp):
+        return self.torch.zeros((rows, kp), dtype=self.torch.float32)
+
+    def load_block(self, block, host_array):
+        block[: host_array.shape[0]].copy_(self.torch.from_numpy(host_array))
+
+    def block_to_host(self, block):
+        return block.numpy().copy()
+
+    def part_rows(self, part):
+        return self.t.part_rows(part)
+
+    def part_init_q(self, part, seed, u_total):
+        return self.t.part_init_q(part, seed, u_total)
+
+    def _sel(self, part):
+        order, _ = self.t.order(part)
+        return order
+
+    def part_train(self, part, block):
+        order = self._sel(part)
+        rows = self.part_rows(part)
+        Qb = np.ascontiguousarray(block.numpy()[:rows, : self.k])
+        self.o.sgd_pass_ordered(self.P, Qb, self.u, self.i // self.G, self.r, order, LR, LAM)
+        block[:rows, : self.k] = self.torch.from_numpy(Qb)
+
+    def part_sse(self, part, block):
+        order = self._sel(part)
+        rows = self.part_rows(part)
+        Qb = np.ascontiguousarray(block.numpy()[:rows, : self.k])
+        return self.o.sse(self.P, Qb, self.u[order], (self.i // self.G)[order], self.r[order])
+
+    def synchronize(self):
+        pass

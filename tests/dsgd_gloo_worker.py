@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""One rank of the gloo DSGD test (launched by tests/test_dsgd_gloo.py through
+torch.distributed.run).  Runs dsgd.DSGD with the CPU stand-in backend over gloo
+and checks the result against the sequential definition on rank 0."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import mfsgd_amd as mf
+from mfsgd_amd.dsgd import DSGD, TorchDistRing, assemble_q
+from tests.dsgd_common import LAM, LR, SEED, OracleBackend, rank_workload, sequential_dsgd
+from tests.oracle_bind import Oracle
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    U_local, I, k, nnz, epochs = 40, 37, 8, 500, 2
+    orc = Oracle()
+    u, i, r = rank_workload(rank, U_local, I, nnz)
+    t = mf.MatrixFactorizationSGD(U_local, I, k, LR, LAM, SEED, n_parts=world)
+    t.set_ratings(u, i, r)
+    t.init_p_offset(SEED, rank * U_local)
+    backend = OracleBackend(torch, orc, t, u, i, r, k, world)
+    ring = TorchDistRing(dist, rank, world)
+    d = DSGD(backend, ring, rank, world, I, t.kp, SEED, U_local * world, nnz)
+    sse = []
+    for _ in range(epochs):
+        d.epoch()
+        assert d.part == rank, "blocks are not home after an epoch"
+        tot, cnt = ring.sum_f64([d.sse(), float(nnz)], torch, torch.device("cpu"))
+        assert cnt == nnz * world
+        sse.append(tot)
+    part, blk = d.home_block()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (rank, backend.P, part, blk))
+    if rank == 0:
+        P = np.concatenate([g[1] for g in sorted(gathered, key=lambda x: x[0])])
+        Q = assemble_q({g[2]: g[3] for g in gathered}, I, k, world)
+        trainers, data = [], []
+        for g in range(world):
+            ug, ig, rg = rank_workload(g, U_local, I, nnz)
+            tg = mf.MatrixFactorizationSGD(U_local, I, k, LR, LAM, SEED, n_parts=world)
+            tg.set_ratings(ug, ig, rg)
+            trainers.append(tg)
+            data.append((ug, ig, rg))
+        Ps, Qs, sse_s = sequential_dsgd(orc, trainers, data, U_local, I, k, world, epochs)
+        assert np.array_equal(P, Ps), "P differs from the sequential DSGD definition"
+        assert np.array_equal(Q, Qs), "Q differs from the sequential DSGD definition"
+        assert np.allclose(sse, sse_s, rtol=1e-12), (sse, sse_s)
+        assert sse[-1] < sse[0]
+        print("dsgd gloo ok", world, sse)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""CPU replay of the device schedule with the kernel's exact memory semantics
+(kernels.hip cell_kernel): rows gathered into an LDS image, the rows of step
+t+1 read BEFORE the rows of step t are written back, flagged q rows forwarded in
+registers, run-mode q rows resident for the whole run.  Arithmetic is the
+oracle's mfo_sgd_update.  If the scheduler ever breaks a hazard rule the replay
+reads a stale row and diverges from the sequential oracle, without needing a GPU.
+"""
+import numpy as np
+
+
+def _decode(x, L):
+    return (int(x) & 0xFFFF) // L, ((int(x) >> 16) & 0x7FFF) // L, (int(x) >> 31) & 1
+
+
+def replay_epoch(oracle, P, Q, k, lr, lam, sched, B, W, G, L):
+    cells, rows, subs, entries = sched
+    for rd in range(B):
+        for b in range(B):
+            cell = b * B + (b + rd) % B
+            row_off, ent_off, n_steps, nuni = (int(v) for v in cells[cell])
+            nu, ni = nuni & 0xFFFF, nuni >> 16
+            nrows = nu + ni
+            if nrows == 0:
+                continue
+            ids = rows[row_off:row_off + nrows]
+            lds = np.zeros((nrows + 2 * G, k), np.float32)
+            lds[:nu] = P[ids[:nu]]
+            lds[nu:nrows] = Q[ids[nu:]]
+
+            def ent(step, g):
+                return entries[(ent_off + step) * G + g]
+
+            for s in range(W):
+                touched = {}
+                for w in range(W):
+                    off, n = (int(v) for v in subs[cell * W * W + s * W + w])
+                    ng, nr = n & 0xFFFF, n >> 16
+                    # ---- general steps --------------------------------------------------
+                    if ng > 0:
+                        cur = []
+                        for g in range(G):
+                            pa, qa, _ = _decode(ent(off, g)[0], L)
+                            cur.append([pa, qa, lds[pa].copy(), lds[qa].copy()])
+                        for t in range(ng):
+                            nxt = []
+                            for g in range(G):  # prefetch of step t+1, before this step's stores
+                                pa, qa, fwd = _decode(ent(off + t + 1, g)[0], L)
+                                nxt.append([pa, qa, lds[pa].copy(), lds[qa].copy(), fwd])
+                            new = []
+                            real_rows = []
+                            for g in range(G):
+                                pa, qa, p, q = cur[g]
+                                r = float(ent(off + t, g)[1:2].view(np.float32)[0])
+                                p2, q2 = p.copy(), q.copy()
+                                oracle.sgd_update(p2, q2, r, lr, lam)
+                                new.append((p2, q2))
+                                if pa < nrows:
+                                    real_rows += [pa, qa]
+                                    for row in (pa, qa):
+                                        assert touched.setdefault(row, w) == w, "row shared by two waves in a sub-round"
+                            assert len(real_rows) == len(set(real_rows)), "two slots of a step share a row"
+                            for g in range(G):
+                                lds[cur[g][0]] = new[g][0]
+                                lds[cur[g][1]] = new[g][1]
+                            for g in range(G):
+                                pa, qa, pn, qn, fwd = nxt[g]
+                                cur[g] = [pa, qa, pn, new[g][1] if fwd else qn]
+                    # ---- run steps ------------------------------------------------------
+                    if nr > 0:
+                        base = off + ng
+                        rqa, rq, curp = [], [], []
+                        for g in range(G):
+                            pa, qa, _ = _decode(ent(base, g)[0], L)
+                            rqa.append(qa)
+                            rq.append(lds[qa].copy())
+                            curp.append([pa, lds[pa].copy()])
+                        assert len(set(rqa)) == len(rqa)
+                        for t in range(nr):
+                            nxtp = []
+                            for g in range(G):
+                                pa, qa, _ = _decode(ent(base + t + 1, g)[0], L)
+                                nxtp.append([pa, lds[pa].copy()])
+                            real_rows = []
+                            for g in range(G):
+                                pa, qa, idle = _decode(ent(base + t, g)[0], L)
+                                assert pa == curp[g][0]
+                                if idle:
+                                    continue
+                                assert qa == rqa[g], "run entry changes the resident item"
+                                r = float(ent(base + t, g)[1:2].view(np.float32)[0])
+                                p2 = curp[g][1].copy()
+                                oracle.sgd_update(p2, rq[g], r, lr, lam)
+                                lds[pa] = p2
+                                real_rows.append(pa)
+                                for row in (pa, qa):
+                                    assert touched.setdefault(row, w) == w, "row shared by two waves in a sub-round"
+                            assert len(real_rows) == len(set(real_rows))
+                            curp = nxtp
+                        for g in range(G):
+                            lds[rqa[g]] = rq[g]
+            assert not lds[nrows:].any(), "an idle slot dirtied the all-zero rows"
+            P[ids[:nu]] = lds[:nu]
+            Q[ids[nu:]] = lds[nu:nrows]

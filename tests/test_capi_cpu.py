@@ -1,0 +1,115 @@
+"""Host-side behaviour of the C-ABI that needs no GPU: the library loads, exports
+every symbol include/mfsgd.h declares, validates arguments, seeds factors like
+java.util.Random, and fails loudly (no CPU fallback) when compute is requested
+without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT, have_gpu
+
+
+def test_exports_every_declared_symbol(mf):
+    hdr = open(os.path.join(ROOT, "include", "mfsgd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mfsgd_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = C.CDLL(mf.library_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in mfsgd.h but not exported"
+    from mfsgd_amd import _lib
+
+    assert declared == set(_lib.SIGNATURES), "ctypes binding out of sync with mfsgd.h"
+    assert lib.mfsgd_abi_version() == 1
+
+
+def test_create_validation(mf):
+    M = mf.MatrixFactorizationSGD
+    for bad in (dict(users=0), dict(items=0), dict(k=0), dict(k=257), dict(waves=3), dict(n_parts=-1)):
+        kw = dict(users=10, items=10, k=8, lr=0.01, lam=0.05, seed=1)
+        extra = {}
+        for key, v in bad.items():
+            if key in kw:
+                kw[key] = v
+            else:
+                extra[key] = v
+        with pytest.raises(mf.MfsgdError):
+            M(kw["users"], kw["items"], kw["k"], kw["lr"], kw["lam"], kw["seed"], **extra)
+    with pytest.raises(mf.MfsgdError) as ei:
+        M(10, 10, 300, 0.01, 0.05, 1)
+    assert ei.value.code == -6  # MFSGD_ERR_UNSUPPORTED
+
+
+def test_set_ratings_validation(mf):
+    with mf.MatrixFactorizationSGD(4, 3, 8, 0.01, 0.05, 1) as m:
+        with pytest.raises(mf.MfsgdError):
+            m.set_ratings([0, 4], [0, 1], [1.0, 2.0])  # user out of range
+        with pytest.raises(mf.MfsgdError):
+            m.set_ratings([0, 1], [0, -1], [1.0, 2.0])
+        with pytest.raises(mf.MfsgdError):
+            m.schedule_info()  # nothing set yet
+        m.set_ratings([], [], [])
+        assert m.schedule_info()["nnz"] == 0
+
+
+def test_init_matches_java_random(mf, oracle):
+    for (U, I, k) in ((7, 5, 8), (3, 9, 5), (2, 2, 64), (4, 4, 100)):
+        with mf.MatrixFactorizationSGD(U, I, k, 0.01, 0.05, 123) as m:
+            m.init_factors()
+            P, Q = m.get_factors()
+        Po, Qo = oracle.init_factors(U, I, k, 123)
+        np.testing.assert_array_equal(P, Po)
+        np.testing.assert_array_equal(Q, Qo)
+
+
+def test_set_get_factors_roundtrip(mf):
+    rng = np.random.default_rng(0)
+    P = rng.random((6, 10), dtype=np.float32)
+    Q = rng.random((4, 10), dtype=np.float32)
+    with mf.MatrixFactorizationSGD(6, 4, 10, 0.01, 0.05, 1) as m:
+        m.set_factors(P, Q)
+        P2, Q2 = m.get_factors()
+    np.testing.assert_array_equal(P, P2)
+    np.testing.assert_array_equal(Q, Q2)
+
+
+def test_part_init_q_is_a_slice_of_the_full_init(mf, oracle):
+    U_total, I, k, G, seed = 11, 13, 6, 3, 77
+    _, Qo = oracle.init_factors(U_total, I, k, seed)
+    with mf.MatrixFactorizationSGD(5, I, k, 0.01, 0.05, seed, n_parts=G) as m:
+        for part in range(G):
+            blk = m.part_init_q(part, seed, U_total)
+            idx = np.arange(part, I, G)
+            assert m.part_rows(part) == idx.size
+            np.testing.assert_array_equal(blk[:, :k], Qo[idx])
+            assert not blk[:, k:].any()
+        # P of a rank that holds users [4, 9)
+        m.init_p_offset(seed, 4)
+        P, _ = m.get_factors()
+    Po, _ = oracle.init_factors(U_total, I, k, seed)
+    np.testing.assert_array_equal(P, Po[4:9])
+
+
+@pytest.mark.skipif(have_gpu(), reason="checks the no-device error path")
+def test_compute_without_device_fails_loudly(mf):
+    with mf.MatrixFactorizationSGD(4, 3, 8, 0.01, 0.05, 1) as m:
+        m.set_ratings([0, 1], [0, 1], [1.0, 2.0])
+        m.init_factors()
+        for call in (lambda: m.fit(1), lambda: m.rmse(), lambda: m.predict([0], [0])):
+            with pytest.raises(mf.MfsgdError) as ei:
+                call()
+            assert ei.value.code == -2  # MFSGD_ERR_NO_DEVICE, never a CPU result
+            assert "no CPU fallback" in str(ei.value) or "device" in str(ei.value)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product tree must not import, link or name anything under oracle/."""
+    pkg = os.path.join(ROOT, "matrixfactorizationsgd.java_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".h", ".java", "Makefile")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "mfsgd_oracle" not in txt and "oracle_bind" not in txt and "mfo_" not in txt, fn

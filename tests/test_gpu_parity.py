@@ -1,54 +1,256 @@
 """Parity of the HIP path (through the C-ABI) against the CPU oracle executing
-the same schedule sequentially.  fp32 arithmetic is specified operation by
+the same schedule sequentially.  The fp32 arithmetic is specified operation by
 operation, so the bar is BIT-EXACT factors; RMSE is
-compared to 1e-9 (fp64 accumulation order differs).  BASELINE.json's stated
-tolerance (RMSE trajectory within 1e-5) is therefore met with margin.
+compared to 1e-9 relative (only the fp64 accumulation order differs).
+BASELINE.json's stated tolerance -- RMSE trajectory within 1e-5 -- is therefore
+met with orders of magnitude to spare, and is also asserted explicitly.
 
-PARITY UNPINNED: the reference holds no code or vectors; "oracle" here is this
-repository's own restatement (oracle/mfsgd_oracle.c)."""
+PARITY UNPINNED: the reference holds no code or vectors
+(/root/reference/README.md:1-2); "oracle" is this repository's own restatement
+(oracle/mfsgd_oracle.c), pinned only by the JDK's java.util.Random
+specification and a hand-computed known answer (tests/test_oracle.py)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 LR, LAM = 0.01, 0.05
+RMSE_TOL = 1e-5  # BASELINE.json: "RMSE within 1e-5 of the reference"
 
 
-def _oracle_train(oracle, w, order, seed, epochs, lr=LR, lam=LAM):
-    P, Q = oracle.init_factors(w["U"], w["I"], w["k"], seed)
+def _oracle_train(oracle, U, I, k, u, i, r, order, seed, epochs, lr=LR, lam=LAM):
+    P, Q = oracle.init_factors(U, I, k, seed)
     rm = []
     for _ in range(epochs):
-        oracle.sgd_pass_ordered(P, Q, w["u"], w["i"], w["r"], order, lr, lam)
-        rm.append(oracle.rmse(P, Q, w["u"], w["i"], w["r"]))
+        oracle.sgd_pass_ordered(P, Q, u, i, r, order, lr, lam)
+        rm.append(oracle.rmse(P, Q, u, i, r))
     return P, Q, np.array(rm)
 
 
-def _run(mf, oracle, w, seed=11, epochs=3, **kw):
-    with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, seed, **kw) as m:
-        rm = m.train(w["u"], w["i"], w["r"], epochs)
+def _run(mf, oracle, U, I, k, u, i, r, seed=11, epochs=3, lr=LR, lam=LAM, **kw):
+    u = np.asarray(u, np.int32)
+    i = np.asarray(i, np.int32)
+    r = np.asarray(r, np.float32)
+    with mf.MatrixFactorizationSGD(U, I, k, lr, lam, seed, **kw) as m:
+        rm = m.train(u, i, r, epochs)
         P, Q = m.get_factors()
         order, cell_ptr = m.order()
         info = m.schedule_info()
-    assert oracle.check_block_schedule(w["u"], w["i"], w["U"], w["I"], order, cell_ptr, info["rounds"], info["blocks"]) == 0
-    Po, Qo, rmo = _oracle_train(oracle, w, order, seed, epochs)
+        rm_again = m.rmse()
+    assert oracle.check_block_schedule(u, i, U, I, order, cell_ptr, info["rounds"], info["blocks"]) == 0
+    Po, Qo, rmo = _oracle_train(oracle, U, I, k, u, i, r, order, seed, epochs, lr, lam)
     assert np.array_equal(P, Po), f"P differs: max abs {np.abs(P - Po).max()}"
     assert np.array_equal(Q, Qo), f"Q differs: max abs {np.abs(Q - Qo).max()}"
-    np.testing.assert_allclose(rm, rmo, rtol=0, atol=1e-9)
-    return rm
+    assert np.abs(rm - rmo).max() <= RMSE_TOL
+    np.testing.assert_allclose(rm, rmo, rtol=1e-9, atol=1e-12)
+    if epochs:
+        assert abs(rm_again - rm[-1]) <= 1e-12
+    return rm, info
 
 
+def _wl(mf, oracle, name, scale=1.0, **kw):
+    w = mf.synth.workload(name, scale)
+    return _run(mf, oracle, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"], **kw)
+
+
+# ---- BASELINE.json configs --------------------------------------------------------
 def test_cfg0_dense(mf, oracle):
-    w = mf.synth.workload("cfg0_dense100x80")
-    rm = _run(mf, oracle, w, epochs=5)
+    rm, _ = _wl(mf, oracle, "cfg0_dense100x80", epochs=5)
     assert rm[-1] < rm[0]
 
 
 def test_cfg1_ml100k(mf, oracle):
-    w = mf.synth.workload("cfg1_ml100k")
-    rm = _run(mf, oracle, w, epochs=3)
+    rm, _ = _wl(mf, oracle, "cfg1_ml100k", epochs=3)
     assert rm[-1] < rm[0]
 
 
 def test_cfg2_ml20m_scaled(mf, oracle):
-    w = mf.synth.workload("cfg2_ml20m", scale=0.05)
-    _run(mf, oracle, w, epochs=2)
+    _wl(mf, oracle, "cfg2_ml20m", scale=0.05, epochs=2)
+
+
+def test_cfg3_netflix_scaled_k128(mf, oracle):
+    _wl(mf, oracle, "cfg3_netflix", scale=0.004, epochs=2)
+
+
+def test_cfg4_powerlaw_scaled_k256(mf, oracle):
+    _wl(mf, oracle, "cfg4_powerlaw", scale=0.0003, epochs=2)
+
+
+# ---- geometry sweep -----------------------------------------------------------------
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 12, 16, 17, 32, 48, 64, 65, 100, 128, 200, 256])
+def test_every_k(mf, oracle, k):
+    rng = np.random.default_rng(k)
+    U, I, n = 300, 200, 12000
+    key = rng.choice(U * I, n, replace=False)
+    _run(mf, oracle, U, I, k, key // I, key % I, rng.random(n) * 4 + 1, epochs=2)
+
+
+@pytest.mark.parametrize("B,W", [(1, 1), (2, 2), (3, 4), (7, 8), (16, 4), (32, 2)])
+def test_blocks_and_waves(mf, oracle, B, W):
+    rng = np.random.default_rng(B * 100 + W)
+    U, I = 900, 700
+    n = min(40000, 200 * B * B)  # a cell must fit the 160 KiB LDS image
+    key = rng.choice(U * I, n, replace=False)
+    _, info = _run(mf, oracle, U, I, 64, key // I, key % I, rng.random(n) * 4 + 1, epochs=2, blocks=B, waves=W)
+    assert info["blocks"] == B and info["waves"] == W
+
+
+def test_eager_launch_equals_graph(mf, oracle):
+    from mfsgd_amd import _lib
+
+    w = mf.synth.workload("cfg1_ml100k", scale=0.5)
+    outs = []
+    for flags in (0, _lib.FLAG_NO_GRAPH):
+        with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 5, flags=flags) as m:
+            m.train(w["u"], w["i"], w["r"], 3)
+            outs.append(m.get_factors())
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+# ---- edge cases -----------------------------------------------------------------------
+def test_edge_cases(mf, oracle):
+    # single rating; pure user chain; pure item chain; duplicates; untouched rows
+    _run(mf, oracle, 5, 5, 8, [2], [3], [4.0])
+    _run(mf, oracle, 1, 40, 8, [0] * 40, list(range(40)), np.arange(40) * 0.1)
+    _run(mf, oracle, 40, 1, 8, list(range(40)), [0] * 40, np.arange(40) * 0.1)
+    _run(mf, oracle, 3, 3, 4, [0, 0, 0, 1, 1, 2, 0], [1, 1, 1, 2, 2, 0, 1], [1, 2, 3, 4, 5, 6, 7])
+    _run(mf, oracle, 50, 50, 12, [49, 49, 49, 0, 7], [0, 49, 25, 0, 7], [1, 2, 3, 4, 5])
+
+
+def test_empty_ratings(mf):
+    with mf.MatrixFactorizationSGD(5, 4, 8, LR, LAM, 1) as m:
+        rm = m.train([], [], [], 2)
+        assert (rm == 0).all()
+        P, Q = m.get_factors()
+        assert np.isfinite(P).all() and np.isfinite(Q).all()
+
+
+def test_hot_item_chain_run_mode(mf, oracle):
+    rng = np.random.default_rng(9)
+    U, I = 3000, 60
+    u = list(range(U)) + list(rng.integers(0, U, 6000))
+    i = [7] * U + list(rng.integers(0, I, 6000))
+    key = np.unique(np.array(u) * I + np.array(i))
+    _run(mf, oracle, U, I, 64, key // I, key % I, rng.random(key.size) * 4 + 1, epochs=2)
+
+
+def test_large_values_and_zero_lambda(mf, oracle):
+    rng = np.random.default_rng(3)
+    U, I, n = 200, 150, 5000
+    key = rng.choice(U * I, n, replace=False)
+    _run(mf, oracle, U, I, 32, key // I, key % I, rng.standard_normal(n) * 50, epochs=2, lr=0.001, lam=0.0)
+
+
+# ---- predict / factors / repeated training ------------------------------------------
+def test_predict_and_set_factors(mf, oracle):
+    rng = np.random.default_rng(4)
+    U, I, k = 120, 90, 40
+    P = rng.standard_normal((U, k)).astype(np.float32)
+    Q = rng.standard_normal((I, k)).astype(np.float32)
+    uu = rng.integers(0, U, 5000).astype(np.int32)
+    ii = rng.integers(0, I, 5000).astype(np.int32)
+    with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 1) as m:
+        m.set_factors(P, Q)
+        out = m.predict(uu, ii)
+        one = m.predict(int(uu[0]), int(ii[0]))
+        P2, Q2 = m.get_factors()
+    np.testing.assert_array_equal(out, oracle.predict(P, Q, uu, ii))
+    assert one == out[0]
+    np.testing.assert_array_equal(P2, P)
+    np.testing.assert_array_equal(Q2, Q)
+
+
+def test_train_twice_and_new_ratings(mf, oracle):
+    w = mf.synth.workload("cfg1_ml100k", scale=0.2)
+    with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 8) as m:
+        r1 = m.train(w["u"], w["i"], w["r"], 2)
+        r2 = m.train(w["u"], w["i"], w["r"], 2)  # continues from the current factors
+        order, _ = m.order()
+        P, Q = m.get_factors()
+        Po, Qo, rmo = _oracle_train(oracle, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"], order, 8, 4)
+        assert np.array_equal(P, Po) and np.array_equal(Q, Qo)
+        np.testing.assert_allclose(np.concatenate([r1, r2]), rmo, rtol=1e-9)
+        # a different rating set on the same handle: new schedule, same factors carried over
+        half = w["nnz"] // 2
+        m.train(w["u"][:half], w["i"][:half], w["r"][:half], 1)
+        order2, _ = m.order()
+        oracle.sgd_pass_ordered(Po, Qo, w["u"][:half], w["i"][:half], w["r"][:half], order2, LR, LAM)
+        P, Q = m.get_factors()
+        assert np.array_equal(P, Po) and np.array_equal(Q, Qo)
+
+
+# ---- DSGD building blocks on one GPU (virtual devices) -------------------------------
+@pytest.mark.parametrize("G", [2, 4])
+def test_dsgd_virtual_devices(mf, oracle, G):
+    import torch
+
+    from tests.dsgd_common import LAM as DL, LR as DLR, SEED, rank_workload, sequential_dsgd
+
+    U_local, I, k, nnz, epochs = 500, 333, 64, 20000, 2
+    dev = torch.device("cuda", 0)
+    trainers, data, blocks = [], [], []
+    for g in range(G):
+        u, i, r = rank_workload(g, U_local, I, nnz)
+        t = mf.MatrixFactorizationSGD(U_local, I, k, DLR, DL, SEED, n_parts=G)
+        t.set_ratings(u, i, r)
+        t.init_p_offset(SEED, g * U_local)
+        trainers.append(t)
+        data.append((u, i, r))
+    kp = trainers[0].kp
+    for part in range(G):
+        blocks.append(torch.from_numpy(trainers[0].part_init_q(part, SEED, U_local * G)).to(dev))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    sse = []
+    for _ in range(epochs):
+        for s in range(G):
+            for g in range(G):
+                part = (g + s) % G
+                trainers[g].part_train(part, blocks[part].data_ptr(), stream)
+        torch.cuda.synchronize()
+        tot = 0.0
+        for s in range(G):
+            for g in range(G):
+                part = (g + s) % G
+                tot += trainers[g].part_sse(part, blocks[part].data_ptr(), stream)
+        sse.append(tot)
+    P = np.concatenate([t.get_factors()[0] for t in trainers])
+    from mfsgd_amd.dsgd import assemble_q
+
+    Q = assemble_q({p: blocks[p].cpu().numpy() for p in range(G)}, I, k, G)
+    Ps, Qs, sse_s = sequential_dsgd(oracle, trainers, data, U_local, I, k, G, epochs)
+    assert np.array_equal(P, Ps) and np.array_equal(Q, Qs)
+    np.testing.assert_allclose(sse, sse_s, rtol=1e-9)
+    for t in trainers:
+        t.close()
+
+
+# ---- BASELINE.json's full size: size-independent properties ---------------------------
+def test_full_size_ml20m_properties(mf, oracle):
+    """20M ratings, k = 64 (the bench workload).  The oracle would need minutes per
+    epoch single-threaded, so the full size is checked through properties:
+    (1) the schedule is a conflict-free permutation of all ratings;
+    (2) two independent handles give bit-identical factors (determinism);
+    (3) the multithreaded oracle on the same schedule reproduces them bit for bit
+        for one epoch (16 threads: seconds);
+    (4) RMSE decreases monotonically over the first epochs and predict() agrees
+        with the factors."""
+    w = mf.synth.workload("cfg2_ml20m")
+    facs, rms = [], []
+    for _ in range(2):
+        with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 3, host_threads=16) as m:
+            rm = m.train(w["u"], w["i"], w["r"], 3)
+            facs.append(m.get_factors())
+            rms.append(rm)
+            order, cell_ptr = m.order()
+            info = m.schedule_info()
+            pr = m.predict(w["u"][:1000], w["i"][:1000])
+    assert oracle.check_block_schedule(w["u"], w["i"], w["U"], w["I"], order, cell_ptr, info["rounds"], info["blocks"]) == 0
+    assert np.array_equal(facs[0][0], facs[1][0]) and np.array_equal(facs[0][1], facs[1][1])
+    assert np.array_equal(rms[0], rms[1])
+    assert rms[0][0] > rms[0][1] > rms[0][2]
+    P, Q = oracle.init_factors(w["U"], w["I"], w["k"], 3)
+    for _ in range(3):
+        oracle.sgd_epoch_mt(P, Q, w["u"], w["i"], w["r"], order, cell_ptr, info["rounds"], info["blocks"], LR, LAM, 16)
+    assert np.array_equal(P, facs[0][0]) and np.array_equal(Q, facs[0][1])
+    assert abs(oracle.rmse(P, Q, w["u"], w["i"], w["r"]) - rms[0][2]) <= 1e-9
+    np.testing.assert_array_equal(pr, oracle.predict(P, Q, w["u"][:1000], w["i"][:1000]))

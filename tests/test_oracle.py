@@ -1,0 +1,131 @@
+"""The CPU oracle against the only external pins that exist (java.util.Random as
+specified by the JDK; the hand-computed KAT of SURVEY.md 8c) and against its own
+committed golden vectors.  PARITY UNPINNED: the reference holds no code, fixture
+or vector (/root/reference/README.md:1-2)."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_jrandom_known_answers(oracle):
+    # java.util.Random: new Random(42).nextInt() and new Random(0).nextInt()
+    assert oracle.jrandom_ints(42, 1)[0] == -1170105035
+    assert oracle.jrandom_ints(0, 1)[0] == -1155484576
+    # second draws follow from the recurrence seed = seed*0x5DEECE66D + 0xB mod 2^48
+    def ref(seed, n):
+        s = (seed ^ 0x5DEECE66D) & ((1 << 48) - 1)
+        out = []
+        for _ in range(n):
+            s = (s * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+            v = s >> 16
+            out.append(v - (1 << 32) if v >= (1 << 31) else v)
+        return out
+    for seed in (0, 1, 42, -7, 2**40 + 12345):
+        assert oracle.jrandom_ints(seed, 16) == ref(seed, 16)
+
+
+def test_jrandom_float_double(oracle):
+    fl = oracle.jrandom_floats(42, 4)
+    assert all(0.0 <= x < 1.0 for x in fl)
+    s = (42 ^ 0x5DEECE66D) & ((1 << 48) - 1)
+    s = (s * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+    assert fl[0] == np.float32((s >> 24) / float(1 << 24))
+    d = oracle.jrandom_doubles(42, 2)
+    assert all(0.0 <= x < 1.0 for x in d)
+    # new Random(42).nextDouble() as printed by the JDK: 0.7275636800328681
+    assert d[0] == 0.7275636800328681
+
+
+def test_hand_kat_2x2(oracle):
+    # e = 0.5 for both ratings, lr = 0.1, lambda = 0
+    P = np.array([[0.5], [0.25]], np.float32)
+    Q = np.array([[1.0], [2.0]], np.float32)
+    oracle.sgd_pass(P, Q, [0, 1], [0, 1], [1.0, 1.0], 0.1, 0.0)
+    np.testing.assert_array_equal(P.ravel(), np.array([0.55, 0.35], np.float32))
+    np.testing.assert_array_equal(Q.ravel(), np.array([1.025, 2.0125], np.float32))
+
+
+def test_update_formula_op_by_op(oracle):
+    # the canonical arithmetic written out in numpy float32, k = 4 (one chunk)
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        p = rng.random(4, dtype=np.float32)
+        q = rng.random(4, dtype=np.float32)
+        r, lr, lam = np.float32(3.25), np.float32(0.01), np.float32(0.05)
+        f = np.float32
+        t0 = f(p[0] * q[0]); t1 = f(p[1] * q[1])
+        t0 = f(np.float64(p[2]) * np.float64(q[2]) + np.float64(t0))  # fma: one rounding
+        t1 = f(np.float64(p[3]) * np.float64(q[3]) + np.float64(t1))
+        dot = f(t0 + t1)
+        assert oracle.dot(p, q) == dot
+        e = f(r - dot); s = f(lr * e); c = f(f(1.0) - f(lr * lam))
+        pe = np.array([f(np.float64(s) * np.float64(q[j]) + np.float64(f(c * p[j]))) for j in range(4)], f)
+        qe = np.array([f(np.float64(s) * np.float64(p[j]) + np.float64(f(c * q[j]))) for j in range(4)], f)
+        p2, q2 = p.copy(), q.copy()
+        err = oracle.sgd_update(p2, q2, float(r), float(lr), float(lam))
+        assert err == e
+        np.testing.assert_array_equal(p2, pe)
+        np.testing.assert_array_equal(q2, qe)
+
+
+def test_dot_close_to_float64(oracle):
+    rng = np.random.default_rng(1)
+    for k in (1, 3, 4, 7, 8, 31, 32, 64, 100, 128, 256):
+        p = rng.standard_normal(k).astype(np.float32)
+        q = rng.standard_normal(k).astype(np.float32)
+        ref = float(np.dot(p.astype(np.float64), q.astype(np.float64)))
+        bound = 2e-6 * float(np.abs(p.astype(np.float64) * q.astype(np.float64)).sum()) + 1e-30
+        assert abs(oracle.dot(p, q) - ref) <= bound
+
+
+def test_init_factors_layout(oracle):
+    P, Q = oracle.init_factors(5, 3, 4, 42)
+    fl = np.array(oracle.jrandom_floats(42, 32), np.float32) * np.float32(1.0 / np.sqrt(4.0))
+    np.testing.assert_array_equal(P.ravel(), fl[:20])
+    np.testing.assert_array_equal(Q.ravel(), fl[20:32])
+
+
+def test_multithreaded_equals_sequential(oracle, mf):
+    w = mf.synth.workload("cfg1_ml100k", scale=0.3)
+    with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], 0.01, 0.05, 1) as m:
+        m.set_ratings(w["u"], w["i"], w["r"])
+        info = m.schedule_info()
+        order, cell_ptr = m.order()
+    P1, Q1 = oracle.init_factors(w["U"], w["I"], w["k"], 9)
+    P2, Q2 = P1.copy(), Q1.copy()
+    for _ in range(2):
+        oracle.sgd_pass_ordered(P1, Q1, w["u"], w["i"], w["r"], order, 0.01, 0.05)
+        oracle.sgd_epoch_mt(P2, Q2, w["u"], w["i"], w["r"], order, cell_ptr, info["rounds"], info["blocks"], 0.01, 0.05, 4)
+    np.testing.assert_array_equal(P1, P2)
+    np.testing.assert_array_equal(Q1, Q2)
+
+
+def test_checker_rejects_bad_schedules(oracle):
+    u = np.array([0, 0, 1, 1], np.int32)
+    i = np.array([0, 1, 0, 1], np.int32)
+    order = np.arange(4, dtype=np.int64)
+    # one round, two cells {0,1} {2,3}: both touch item 0 -> conflict
+    assert oracle.check_block_schedule(u, i, 2, 2, order, np.array([0, 2, 4], np.int64), 1, 2) == 2
+    # two rounds of two cells, diagonal: ok
+    order = np.array([0, 3, 1, 2], np.int64)
+    assert oracle.check_block_schedule(u, i, 2, 2, order, np.array([0, 1, 2, 3, 4], np.int64), 2, 2) == 0
+    # not a permutation
+    order = np.array([0, 0, 1, 2], np.int64)
+    assert oracle.check_block_schedule(u, i, 2, 2, order, np.array([0, 1, 2, 3, 4], np.int64), 2, 2) == 1
+
+
+def test_golden_vectors(oracle, mf):
+    """Self-generated fixtures (tests/golden/make_golden.py): RMSE trajectory and factor
+    checksums of the oracle in natural rating order.  They pin the oracle against
+    accidental change; they are NOT reference outputs (none exist)."""
+    with open(os.path.join(HERE, "golden", "oracle_golden.json")) as f:
+        gold = json.load(f)
+    from tests.golden.make_golden import run_case
+
+    for case in gold["cases"]:
+        got = run_case(oracle, mf, case["workload"], case["scale"], case["seed"], case["epochs"], case["lr"], case["lambda"])
+        assert got["rmse"] == case["rmse"], case["workload"]
+        assert got["p_sha256"] == case["p_sha256"] and got["q_sha256"] == case["q_sha256"], case["workload"]

@@ -1,0 +1,122 @@
+"""The host scheduler, without a GPU: every schedule is a conflict-free
+permutation (oracle checker), and replaying the device arrays with the kernel's
+exact LDS access order (tests/kernel_emulator.py) reproduces the sequential
+oracle bit for bit -- i.e. the hazard rules the pipelined kernel relies on hold."""
+import numpy as np
+import pytest
+
+from tests.kernel_emulator import replay_epoch
+
+LR, LAM = 0.01, 0.05
+
+
+def _check(mf, oracle, U, I, k, u, i, r, replay=True, **kw):
+    u = np.asarray(u, np.int32)
+    i = np.asarray(i, np.int32)
+    r = np.asarray(r, np.float32)
+    with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 3, **kw) as m:
+        m.set_ratings(u, i, r)
+        info = m.schedule_info()
+        order, cell_ptr = m.order()
+        sched = m.debug_schedule()
+    assert info["nnz"] == u.size
+    assert oracle.check_block_schedule(u, i, U, I, order, cell_ptr, info["rounds"], info["blocks"]) == 0
+    if replay and u.size:
+        P, Q = oracle.init_factors(U, I, k, 3)
+        Pe, Qe = P.copy(), Q.copy()
+        for _ in range(2):
+            oracle.sgd_pass_ordered(P, Q, u, i, r, order, LR, LAM)
+            replay_epoch(oracle, Pe, Qe, k, LR, LAM, sched, info["blocks"], info["waves"], info["slots"], info["group_lanes"])
+        np.testing.assert_array_equal(Pe, P)
+        np.testing.assert_array_equal(Qe, Q)
+    return info
+
+
+def test_cfg0_dense(mf, oracle):
+    w = mf.synth.workload("cfg0_dense100x80")
+    _check(mf, oracle, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"])
+
+
+def test_cfg1_scaled(mf, oracle):
+    w = mf.synth.workload("cfg1_ml100k", scale=0.2)
+    _check(mf, oracle, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"])
+
+
+def test_cfg2_scaled_skewed(mf, oracle):
+    w = mf.synth.workload("cfg2_ml20m", scale=0.002)
+    info = _check(mf, oracle, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"])
+    assert info["slots"] == 4 and info["group_lanes"] == 16
+
+
+@pytest.mark.parametrize("k", [1, 3, 4, 5, 8, 17, 32, 64, 100, 128, 200, 256])
+def test_all_geometries(mf, oracle, k):
+    rng = np.random.default_rng(k)
+    U, I, n = 60, 45, 900
+    key = rng.choice(U * I, n, replace=False)
+    info = _check(mf, oracle, U, I, k, key // I, key % I, rng.random(n) * 4 + 1)
+    L = info["group_lanes"]
+    assert L * info["slots"] == 64 and info["kp"] == 4 * L and 4 * L >= k
+
+
+@pytest.mark.parametrize("B,W", [(1, 1), (2, 1), (3, 2), (4, 4), (5, 8)])
+def test_explicit_blocks_and_waves(mf, oracle, B, W):
+    rng = np.random.default_rng(B * 10 + W)
+    U, I, n = 80, 70, 1500
+    key = rng.choice(U * I, n, replace=False)
+    info = _check(mf, oracle, U, I, 16, key // I, key % I, rng.random(n), blocks=B, waves=W)
+    assert info["blocks"] == B and info["waves"] == W
+
+
+def test_edge_cases(mf, oracle):
+    # empty
+    _check(mf, oracle, 5, 5, 8, [], [], [])
+    # a single rating
+    _check(mf, oracle, 5, 5, 8, [2], [3], [4.0])
+    # one user rating everything / one item rated by everyone (pure chains)
+    _check(mf, oracle, 1, 40, 8, [0] * 40, list(range(40)), np.arange(40) * 0.1)
+    _check(mf, oracle, 40, 1, 8, list(range(40)), [0] * 40, np.arange(40) * 0.1)
+    # duplicate (u, i) pairs: legal input, must be applied one after the other
+    _check(mf, oracle, 3, 3, 4, [0, 0, 0, 1, 1, 2, 0], [1, 1, 1, 2, 2, 0, 1], [1, 2, 3, 4, 5, 6, 7])
+    # users / items that never occur, ragged degrees
+    _check(mf, oracle, 50, 50, 12, [49, 49, 49, 0, 7], [0, 49, 25, 0, 7], [1, 2, 3, 4, 5])
+
+
+def test_hot_item_runs(mf, oracle):
+    # one item rated by 300 users + background: exercises run mode (resident q rows)
+    rng = np.random.default_rng(9)
+    U, I = 300, 50
+    u = list(range(U)) + list(rng.integers(0, U, 600))
+    i = [7] * U + list(rng.integers(0, I, 600))
+    key = np.unique(np.array(u) * I + np.array(i))
+    info = _check(mf, oracle, U, I, 64, key // I, key % I, rng.random(key.size), blocks=2, waves=2)
+    assert info["total_steps"] > 0
+
+
+def test_schedule_is_deterministic(mf):
+    w = mf.synth.workload("cfg1_ml100k", scale=0.3)
+    orders = []
+    for threads in (1, 4):
+        with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 3, host_threads=threads) as m:
+            m.set_ratings(w["u"], w["i"], w["r"])
+            orders.append(m.order()[0])
+    np.testing.assert_array_equal(orders[0], orders[1])
+
+
+def test_partitioned_schedules_cover_everything(mf, oracle):
+    w = mf.synth.workload("cfg1_ml100k", scale=0.3)
+    G = 3
+    with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 3, n_parts=G) as m:
+        m.set_ratings(w["u"], w["i"], w["r"])
+        seen = np.zeros(w["nnz"], bool)
+        for part in range(G):
+            order, cell_ptr = m.order(part)
+            info = m.schedule_info(part)
+            assert (w["i"][order] % G == part).all()
+            assert not seen[order].any()
+            seen[order] = True
+            # conflict-free within the partition (local item ids)
+            sel = order
+            remap = {x: j for j, x in enumerate(sel)}
+            assert oracle.check_block_schedule(w["u"][sel], w["i"][sel] // G, w["U"], m.part_rows(part),
+                                               np.arange(sel.size, dtype=np.int64), cell_ptr, info["rounds"], info["blocks"]) == 0
+        assert seen.all()
