@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--round-launch", action="store_true", help="one kernel per round instead of the persistent epoch kernel")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,7 +131,7 @@ def main():
     if rank == 0:
         log(f"generated {w['nnz']} ratings ({w['U']} x {w['I']}, {w['dist']}) in {time.time() - t0:.1f} s")
     k, nnz = w["k"], w["nnz"]
-    flags = _lib.FLAG_NO_GRAPH if args.no_graph else 0
+    flags = (_lib.FLAG_NO_GRAPH if args.no_graph else 0) | (_lib.FLAG_ROUND_LAUNCH if args.round_launch else 0)
 
     m = mfsgd_amd.MatrixFactorizationSGD(w["U"], w["I"], k, LR, LAM, SEED, device=local_rank, blocks=args.blocks,
                                          waves=args.waves, n_parts=world if world > 1 else 0,
@@ -143,7 +144,7 @@ def main():
         log(f"schedule built in {time.time() - t0:.1f} s: B={i0['blocks']} W={i0['waves']} G={i0['slots']} "
             f"lds={i0['lds_bytes']} steps={sum(i['total_steps'] for i in infos)} rows={sum(i['total_rows'] for i in infos)}")
 
-    launches_per_epoch = sum(i["rounds"] for i in infos if i["nnz"] > 0)
+    launches_per_epoch = sum((i["rounds"] if args.round_launch else 1) for i in infos if i["nnz"] > 0)
 
     if world == 1:
         m.init_factors(SEED)
@@ -200,7 +201,8 @@ def main():
     achieved_gbs = units_per_launch * bytes_per_update / avg_launch_s / 1e9
     roofline = {
         "bound": "hbm",
-        "kernel": "mfsgd::cell_kernel<L,W,train> (one launch per round)",
+        "kernel": ("mfsgd::epoch_kernel<L,W> (persistent: one launch per epoch)" if launches == args.steps
+                   else "mfsgd::cell_kernel<L,W,train> (one launch per round)"),
         "achieved": achieved_gbs,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",

@@ -66,7 +66,9 @@ typedef struct mfsgd_config {
     int32_t reserved[5];  /* must be zero                                           */
 } mfsgd_config;
 
-#define MFSGD_FLAG_NO_GRAPH 1 /* launch rounds eagerly instead of via a hipGraph */
+#define MFSGD_FLAG_NO_GRAPH 1     /* launch eagerly instead of replaying a hipGraph            */
+#define MFSGD_FLAG_ROUND_LAUNCH 2 /* one kernel launch per round instead of the persistent      */
+                                  /* epoch kernel (which hands item tiles between workgroups)   */
 
 /* What the scheduler built; for tests, bench.py's roofline arithmetic, DESIGN. */
 typedef struct mfsgd_schedule_info {
@@ -77,7 +79,7 @@ typedef struct mfsgd_schedule_info {
     int32_t group_lanes;  /* L: lanes per rating (row bytes / 16)                   */
     int32_t slots;        /* G = 64 / L ratings per wave step                       */
     int32_t kp;           /* padded row length in floats (device stride)            */
-    int32_t rounds;       /* kernel launches per epoch (= B)                        */
+    int32_t rounds;       /* rounds per epoch (= B)                                 */
     int32_t lds_bytes;    /* dynamic LDS requested per workgroup                    */
     int64_t total_steps;  /* wave steps over all cells                              */
     int64_t total_rows;   /* factor rows gathered (and scattered) per epoch         */
@@ -151,8 +153,9 @@ int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cell
                              uint32_t* subs, uint32_t* entries);
 
 /* Diagnostic (not part of the Java surface): runs training round `round` once with
- * phase stamps; out receives blocks x 4 shader-clock values per workgroup:
- * start, after gather, after the rating steps, after scatter.  It DOES apply
+ * phase stamps; out receives blocks x 6 values per workgroup: shader-clock at
+ * start, after gather, after the rating steps, after scatter, then the 100 MHz
+ * constant clock at start and at end.  It DOES apply
  * that round's updates.  Single-partition handles only.                        */
 int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint64_t* out);
 

@@ -52,6 +52,7 @@ class ScheduleInfo(C.Structure):
 
 
 FLAG_NO_GRAPH = 1
+FLAG_ROUND_LAUNCH = 2
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)

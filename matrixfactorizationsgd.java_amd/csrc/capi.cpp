@@ -6,6 +6,7 @@
 // device and fails with MFSGD_ERR_NO_DEVICE otherwise.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -42,6 +43,8 @@ struct Part {
     int32_t q_rows = 0;  // rows of this partition's Q block
     bool on_device = false;
     DevBuf d_cells, d_rows, d_subs, d_entries, d_sse_partial, d_sse_out;
+    DevBuf d_sync;        // persistent kernel: done[B] words (kDoneStride apart) + the abort word
+    int persistent_np = -1;  // co-resident workgroups of the epoch kernel; 0 = use round launches; -1 = not probed
     // training graphs keyed by the Q block pointer they were captured with
     std::map<const void*, hipGraphExec_t> graphs;
 };
@@ -62,6 +65,7 @@ struct mfsgd_handle {
     DevBuf dP, dQ;
 
     bool device_ready = false;
+    int n_cu = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     mutable std::string err;
@@ -112,6 +116,7 @@ int ensure_device(mfsgd_handle* h) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(h, MFSGD_ERR_NO_DEVICE,
                     std::string("device is ") + prop.gcnArchName + "; libmfsgd is built for gfx950 only");
+    h->n_cu = prop.multiProcessorCount;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreate(&h->ev0));
@@ -143,6 +148,9 @@ void drop_graphs(Part& p) {
     p.graphs.clear();
 }
 
+size_t sync_bytes(const Part& p) { return ((size_t)p.sched.B * kDoneStride + 4) * sizeof(unsigned); }
+unsigned* abort_word(const Part& p) { return static_cast<unsigned*>(p.d_sync.p) + (size_t)p.sched.B * kDoneStride; }
+
 int ensure_part_on_device(mfsgd_handle* h, Part& p) {
     if (p.on_device) return MFSGD_OK;
     int rc;
@@ -152,6 +160,8 @@ int ensure_part_on_device(mfsgd_handle* h, Part& p) {
     if ((rc = upload(h, p.d_entries, p.sched.entries))) return rc;
     if ((rc = dev_alloc(h, p.d_sse_partial, sizeof(double) * (size_t)p.sched.B * p.sched.B))) return rc;
     if ((rc = dev_alloc(h, p.d_sse_out, sizeof(double)))) return rc;
+    if ((rc = dev_alloc(h, p.d_sync, sync_bytes(p)))) return rc;
+    HIPCHK(h, hipMemset(p.d_sync.p, 0, sync_bytes(p)));
     p.on_device = true;
     return MFSGD_OK;
 }
@@ -198,17 +208,49 @@ int launch_epoch_eager(mfsgd_handle* h, Part& p, float* Q, hipStream_t st) {
     return MFSGD_OK;
 }
 
+// The persistent epoch kernel needs every one of its workgroups resident at once.
+int probe_persistent(mfsgd_handle* h, Part& p) {
+    if (p.persistent_np >= 0) return MFSGD_OK;
+    p.persistent_np = 0;
+    if (h->cfg.flags & MFSGD_FLAG_ROUND_LAUNCH) return MFSGD_OK;
+    CellLaunch a = make_launch(h, p, nullptr);
+    int per_cu = 0;
+    hipError_t e = epoch_blocks_per_cu(h->geo.L, p.sched.W, a, &per_cu);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return MFSGD_OK;  // fall back to one launch per round
+    }
+    const long np = (long)per_cu * h->n_cu;
+    p.persistent_np = (int)std::min<long>(np, p.sched.B);
+    return MFSGD_OK;
+}
+
+int launch_epoch_body(mfsgd_handle* h, Part& p, float* Q, hipStream_t st) {
+    if (p.persistent_np > 0) {
+        CellLaunch a = make_launch(h, p, Q);
+        a.grid = p.persistent_np;
+        // flags are counted within the launch: zero them (and the abort word) every time
+        HIPCHK(h, hipMemsetAsync(p.d_sync.p, 0, sync_bytes(p) - sizeof(unsigned) * 4, st));
+        HIPCHK(h, launch_epoch_persistent(h->geo.L, p.sched.W, a, p.sched.B, static_cast<unsigned*>(p.d_sync.p),
+                                          abort_word(p), st));
+        return MFSGD_OK;
+    }
+    return launch_epoch_eager(h, p, Q, st);
+}
+
 // One epoch of partition p against Q on stream st (asynchronous).
 int launch_epoch(mfsgd_handle* h, Part& p, float* Q, hipStream_t st) {
     if (p.sched.nnz == 0) return MFSGD_OK;
-    if (h->cfg.flags & MFSGD_FLAG_NO_GRAPH) return launch_epoch_eager(h, p, Q, st);
+    int rc = probe_persistent(h, p);
+    if (rc) return rc;
+    if (h->cfg.flags & MFSGD_FLAG_NO_GRAPH) return launch_epoch_body(h, p, Q, st);
     auto it = p.graphs.find(Q);
     if (it == p.graphs.end()) {
-        // capture the B round launches once; replayed every epoch
+        // capture the launch(es) of one epoch once; replayed every epoch
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        int rc = launch_epoch_eager(h, p, Q, h->stream);
+        rc = launch_epoch_body(h, p, Q, h->stream);
         hipError_t e = hipStreamEndCapture(h->stream, &graph);
         if (rc) {
             if (graph) (void)hipGraphDestroy(graph);
@@ -222,6 +264,18 @@ int launch_epoch(mfsgd_handle* h, Part& p, float* Q, hipStream_t st) {
         it = p.graphs.emplace(Q, exec).first;
     }
     HIPCHK(h, hipGraphLaunch(it->second, st));
+    return MFSGD_OK;
+}
+
+// After a synchronisation point: did a persistent launch give up on a hand-off?
+int check_abort(mfsgd_handle* h, Part& p) {
+    if (p.persistent_np <= 0 || !p.d_sync.p) return MFSGD_OK;
+    unsigned w = 0;
+    HIPCHK(h, hipMemcpy(&w, abort_word(p), sizeof w, hipMemcpyDeviceToHost));
+    if (w != 0) {
+        (void)hipMemset(abort_word(p), 0, sizeof w);
+        return fail(h, MFSGD_ERR_HIP, "persistent epoch kernel timed out waiting for a tile hand-off (results invalid)");
+    }
     return MFSGD_OK;
 }
 
@@ -242,7 +296,7 @@ int part_sse_sync(mfsgd_handle* h, Part& p, const float* Q, hipStream_t st, doub
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(sse, p.d_sse_out.p, sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
-    return MFSGD_OK;
+    return check_abort(h, p);
 }
 
 int prepare_compute(mfsgd_handle* h) {
@@ -329,6 +383,7 @@ void mfsgd_destroy(mfsgd_handle* h) {
         p.d_entries.release();
         p.d_sse_partial.release();
         p.d_sse_out.release();
+        p.d_sync.release();
     }
     h->dP.release();
     h->dQ.release();
@@ -357,6 +412,7 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
             p.d_entries.release();
             p.d_sse_partial.release();
             p.d_sse_out.release();
+            p.d_sync.release();
         }
         h->parts.clear();
         h->have_ratings = false;
@@ -527,7 +583,7 @@ int mfsgd_train(mfsgd_handle* h, int32_t epochs, double* rmse_per_epoch) {
         }
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return MFSGD_OK;
+    return check_abort(h, p);
 }
 
 int mfsgd_train_timed(mfsgd_handle* h, int32_t epochs, double* elapsed_ms, int64_t* launches) {
@@ -546,8 +602,8 @@ int mfsgd_train_timed(mfsgd_handle* h, int32_t epochs, double* elapsed_ms, int64
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *elapsed_ms = (double)ms;
-    if (launches) *launches = p.sched.nnz > 0 ? (int64_t)epochs * p.sched.B : 0;
-    return MFSGD_OK;
+    if (launches) *launches = p.sched.nnz > 0 ? (int64_t)epochs * (p.persistent_np > 0 ? 1 : p.sched.B) : 0;
+    return check_abort(h, p);
 }
 
 int mfsgd_rmse(mfsgd_handle* h, double* out) {
@@ -665,12 +721,12 @@ int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint6
     if (rc) return rc;
     Part& p = h->parts[0];
     if (round < 0 || round >= p.sched.B) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_round_stamps: bad round");
-    if ((size_t)p.sched.B * 4 * sizeof(uint64_t) > p.d_sse_partial.bytes) return fail(h, MFSGD_ERR_STATE, "debug_round_stamps: buffer too small");
+    if ((size_t)p.sched.B * 6 * sizeof(uint64_t) > p.d_sse_partial.bytes) return fail(h, MFSGD_ERR_STATE, "debug_round_stamps: buffer too small");
     CellLaunch a = make_launch(h, p, static_cast<float*>(h->dQ.p));
     a.rd = round;
     a.diag = true;
     HIPCHK(h, launch_cell(true, h->geo.L, p.sched.W, a, h->stream));
-    HIPCHK(h, hipMemcpyAsync(out, p.d_sse_partial.p, (size_t)p.sched.B * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out, p.d_sse_partial.p, (size_t)p.sched.B * 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return MFSGD_OK;
 }

@@ -70,6 +70,7 @@ __device__ __forceinline__ float4 axpy_row(const float s, const float4 x, const 
 
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ float4 lds_ld(const unsigned char* base, unsigned off) {
     return *reinterpret_cast<const float4*>(base + off);
@@ -78,239 +79,368 @@ __device__ __forceinline__ void lds_st(unsigned char* base, unsigned off, const 
     *reinterpret_cast<float4*>(base + off) = v;
 }
 
-// One workgroup = one cell.  TRAIN: round `rd` runs cells (b, (b + rd) % B).
-// !TRAIN: blockIdx.x is the cell index, no writes, sum of squared errors out.
+// Everything one workgroup does with one cell, phase by phase.  Shared by the
+// per-round kernel, the SSE pass and the persistent epoch kernel.
 //
-// LDS image: [rows: nrows x ROWB][2G zero rows][entries: n_steps x G x 8][subs: W*W x 8][row ids: nrows x 4]
-template <int L, int W, bool TRAIN, bool DIAG = false>
-__global__ void __launch_bounds__(64 * W)
-cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __restrict__ cells,
-            const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs,
-            const Entry* __restrict__ entries, const int B, const int rd, const float lr,
-            const float c, double* __restrict__ sse_partial) {
-    constexpr int G = 64 / L;
-    constexpr int ROWB = 16 * L;
-    constexpr int KP = 4 * L;
-    constexpr int NT = 64 * W;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// LDS image (after a 16-byte control block):
+//   [rows: nrows x ROWB][2G zero rows][entries: n_steps x G x 8][subs: W*W x 8][row ids: nrows x 4]
+// rows: LDS slots [0, nu) hold p-side (user) rows, [nu, nrows) q-side (item) rows.
+template <int L, int W>
+struct Cell {
+    static constexpr int G = 64 / L;
+    static constexpr int ROWB = 16 * L;
+    static constexpr int KP = 4 * L;
+    static constexpr int NT = 64 * W;
+    static constexpr int CTL = 16;  // control block at the start of the dynamic LDS
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane / L;
-    const int lig = lane % L;
-    const int cell = TRAIN ? (int)blockIdx.x * B + ((int)blockIdx.x + rd) % B : (int)blockIdx.x;
-    const CellDesc cd = cells[cell];
-    unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
-    if constexpr (DIAG) stamp0 = __builtin_amdgcn_s_memtime();
-    const int nu = cd.nu;
-    const int nrows = (int)cd.nu + (int)cd.ni;
-    if (nrows == 0) {  // uniform over the workgroup
-        if (!TRAIN && tid == 0) sse_partial[cell] = 0.0;
-        return;
+    int tid, lane, wave, g, lig;
+    unsigned laneoff;
+    int nu, nrows, n_steps;
+    unsigned char* lrows;
+    uint2* lent;
+    uint2* lsub;
+    uint32_t* lids;
+
+    __device__ __forceinline__ void init_thread() {
+        tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        g = lane / L;
+        lig = lane % L;
+        laneoff = (unsigned)lig * 16u;
     }
-    unsigned char* const lrows = smem;
-    uint2* const lent = reinterpret_cast<uint2*>(smem + (size_t)(nrows + 2 * G) * ROWB);
-    uint2* const lsub = lent + (size_t)cd.n_steps * G;
-    uint32_t* const lids = reinterpret_cast<uint32_t*>(lsub + W * W);
+    __device__ __forceinline__ void bind(const CellDesc& cd, unsigned char* smem) {
+        nu = cd.nu;
+        nrows = (int)cd.nu + (int)cd.ni;
+        n_steps = (int)cd.n_steps;
+        lrows = smem + CTL;
+        lent = reinterpret_cast<uint2*>(lrows + (size_t)(nrows + 2 * G) * ROWB);
+        lsub = lent + (size_t)n_steps * G;
+        lids = reinterpret_cast<uint32_t*>(lsub + W * W);
+    }
 
-    // ---- stage the cell's schedule: row ids, step entries, sub-cell table ---------
-    // (one global latency for all of it; the row gather below depends on the ids)
-    const uint32_t* const crow = rows + cd.row_off;
-    for (int x = tid; x < nrows; x += NT) lids[x] = crow[x];
-    {
+    // Row ids, step entries and the sub-cell table -> LDS; zeroes the idle rows.
+    // One global latency for all of it.  Caller barriers before using any of it.
+    __device__ __forceinline__ void stage_schedule(const CellDesc& cd, int cell, const uint32_t* __restrict__ rows,
+                                                   const SubDesc* __restrict__ subs,
+                                                   const Entry* __restrict__ entries) {
+        const uint32_t* const crow = rows + cd.row_off;
+        for (int x = tid; x < nrows; x += NT) lids[x] = crow[x];
         const uint2* gent = reinterpret_cast<const uint2*>(entries) + (size_t)cd.ent_off * G;
-        const int ne = (int)cd.n_steps * G;
+        const int ne = n_steps * G;
         for (int x = tid; x < ne; x += NT) lent[x] = gent[x];
         if (tid < W * W) lsub[tid] = reinterpret_cast<const uint2*>(subs)[(size_t)cell * W * W + tid];
+        // idle slots of a step point at these all-zero rows: r = 0 keeps them zero
+        for (int x = tid; x < 2 * G * L; x += NT)
+            lds_st(lrows, (unsigned)(nrows * ROWB + x * 16), make_float4(0.f, 0.f, 0.f, 0.f));
     }
-    // idle slots of a step point at these all-zero rows: r = 0 keeps them zero
-    for (int x = tid; x < 2 * G * L; x += NT)
-        lds_st(lrows, (unsigned)(nrows * ROWB + x * 16), make_float4(0.f, 0.f, 0.f, 0.f));
-    __syncthreads();
 
-    // ---- gather: touched factor rows -> LDS, straight from memory (LDS-DMA) -------
-    // One wave instruction moves G whole rows (64 lanes x 16 B = G x ROWB contiguous
-    // LDS bytes); the source address is per lane, so it is a row gather.  Every load
-    // of the wave is in flight before the single wait.
-    for (int s0 = wave * G; s0 < nrows; s0 += W * G) {
-        const int sx = s0 + g;
-        if (sx < nrows) {
-            const uint32_t rid = lids[sx];
-            const float* src = (sx < nu ? P : Q) + (size_t)rid * KP + lig * 4;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lrows + (size_t)s0 * ROWB), 16, 0, 0);
+    // Factor rows of LDS slots [lo, hi) -> LDS, straight from memory (LDS-DMA).  One
+    // wave instruction moves G whole rows (64 lanes x 16 B = G x ROWB contiguous LDS
+    // bytes); the source address is per lane, so it is a row gather.  Issues every
+    // load of the wave back to back and does NOT wait: caller does vmcnt(0) + barrier.
+    __device__ __forceinline__ void gather(const float* __restrict__ P, const float* __restrict__ Q, int lo, int hi) {
+        const int first = (lo / G) * G;  // keep wave instructions aligned to G-slot groups
+        for (int s0 = first + wave * G; s0 < hi; s0 += W * G) {
+            const int sx = s0 + g;
+            if (sx >= lo && sx < hi) {
+                const uint32_t rid = lids[sx];
+                const float* src = (sx < nu ? P : Q) + (size_t)rid * KP + lig * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lrows + (size_t)s0 * ROWB), 16, 0, 0);
+            }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if constexpr (DIAG) stamp1 = __builtin_amdgcn_s_memtime();
+
+    // LDS slots [lo, hi) -> factor rows.  WT: write-through (sc1) stores, for rows another
+    // workgroup will read inside the same launch (cdna guide, Guideline 16, form R1).
+    template <bool WT>
+    __device__ __forceinline__ void scatter(float* __restrict__ P, float* __restrict__ Q, int lo, int hi) {
+        for (int s = lo + wave * G + g; s < hi; s += W * G) {
+            const uint32_t rid = lids[s];
+            float* dst = (s < nu ? P : Q) + (size_t)rid * KP + lig * 4;
+            const float4 v = lds_ld(lrows, (unsigned)(s * ROWB) + laneoff);
+            if constexpr (WT) {
+                const f32x4 vv = {v.x, v.y, v.z, v.w};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
+            } else {
+                *reinterpret_cast<float4*>(dst) = v;
+            }
+        }
+    }
 
     // ---- apply the ratings out of LDS ------------------------------------------
     // Software pipeline: the rows of step t+1 are read before the rows of step t are
     // written back.  The scheduler guarantees (schedule.cpp, "Eligibility") that a
     // row read that early was not written in step t, except a q-side row in the same
     // lane slot, which is flagged and taken from registers instead.
-    double acc = 0.0;
-    const unsigned laneoff = (unsigned)lig * 16u;
-    // Two register sets (A, B) alternate between "current step" and "next step", so
-    // the loop is unrolled by two and nothing is copied between iterations.
     struct StepRegs {
-        uint2 en;      // entry: addresses | forward flag, rating
+        uint2 en;  // entry: addresses | flag, rating
         unsigned pa, qa;
         float4 p, q;
     };
-    auto set_addr = [&](StepRegs& x) {
-        x.pa = ((x.en.x & 0xFFFFu) << 4) + laneoff;
-        x.qa = (__builtin_amdgcn_ubfe(x.en.x, 16, 15) << 4) + laneoff;
-    };
-    // One step: `cur` holds step t (entry, addresses, rows); `nxt.en` holds entry t+1.
-    // Leaves `nxt` complete for step t+1 and cur.en = entry t+2 (read from eptr[e2]).
-    auto step = [&](StepRegs& cur, StepRegs& nxt, const uint2* eptr, const int e2) {
-        const float r = __builtin_bit_cast(float, cur.en.y);
-        set_addr(nxt);
-        const float4 pn = lds_ld(lrows, nxt.pa);
-        const float4 qn = lds_ld(lrows, nxt.qa);
-        cur.en = eptr[e2];
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
-        const float dot = group_allreduce<L>(chunk_dot(cur.p, cur.q));
-        const float err = r - dot;
-        if constexpr (TRAIN) {
-            const float sc = lr * err;
-            const float4 p2 = axpy_row(sc, cur.q, c, cur.p);
-            const float4 q2 = axpy_row(sc, cur.p, c, cur.q);
-            lds_st(lrows, cur.pa, p2);
-            lds_st(lrows, cur.qa, q2);
-            const bool fwd = (int)nxt.en.x < 0;
-            nxt.q.x = fwd ? q2.x : qn.x;
-            nxt.q.y = fwd ? q2.y : qn.y;
-            nxt.q.z = fwd ? q2.z : qn.z;
-            nxt.q.w = fwd ? q2.w : qn.w;
-        } else {
-            acc += (double)err * (double)err;
-            nxt.q = qn;
-        }
-        nxt.p = pn;
-    };
-    // Run step: the slot's q row is resident in `rq` for the whole run (no q load, no
-    // select, no q store); idle slots (flag bit) skip the update.
-    float4 rq;
-    auto run_step = [&](StepRegs& cur, StepRegs& nxt, const uint2* eptr, const int e2) {
-        const float r = __builtin_bit_cast(float, cur.en.y);
-        const bool active = (int)cur.en.x >= 0;
-        nxt.pa = ((nxt.en.x & 0xFFFFu) << 4) + laneoff;
-        const float4 pn = lds_ld(lrows, nxt.pa);
-        cur.en = eptr[e2];
-        const float dot = group_allreduce<L>(chunk_dot(cur.p, rq));
-        const float err = r - dot;
-        if constexpr (TRAIN) {
-            // idle slot: s = 0 and c = 1 leave the resident row bit-identical
-            // (fma(0, p, 1*q) == q) and rewrite zeros to the all-zero p row.
-            const float sc = active ? lr * err : 0.0f;
-            const float ce = active ? c : 1.0f;
-            const float4 p2 = axpy_row(sc, rq, ce, cur.p);
-            rq = axpy_row(sc, cur.p, ce, rq);
-            lds_st(lrows, cur.pa, p2);
-        } else {
-            acc += (double)err * (double)err;  // idle: p row and r are zero, err == 0
-        }
-        nxt.p = pn;
-    };
-    for (int s = 0; s < W; ++s) {
-        const uint2 sd = lsub[s * W + wave];
-        const int nall = __builtin_amdgcn_readfirstlane((int)sd.y);
-        const int n = nall & 0xFFFF;   // general steps
-        const int nr = nall >> 16;     // run steps, stored after the general ones
-        // entries of this wave's sub-cell; the host pads every cell with two idle
-        // steps, so reading entries t+1 and t+2 past the end stays inside the image
-        const uint2* ebase = lent + (size_t)__builtin_amdgcn_readfirstlane((int)sd.x) * G + g;
-        if (n > 0) {
-            const uint2* eptr = ebase;
-            StepRegs A, B;
-            A.en = eptr[0];
-            B.en = eptr[G];
-            set_addr(A);
-            A.p = lds_ld(lrows, A.pa);
-            A.q = lds_ld(lrows, A.qa);
-            int t = 0;
-            for (; t + 1 < n; t += 2, eptr += 2 * G) {
-                step(A, B, eptr, 2 * G);
-                step(B, A, eptr, 3 * G);
+
+    template <bool TRAIN>
+    __device__ __forceinline__ void apply(const float lr, const float c, double& acc) {
+        unsigned char* const lr_ = lrows;
+        const unsigned lo = laneoff;
+        auto set_addr = [&](StepRegs& x) {
+            x.pa = ((x.en.x & 0xFFFFu) << 4) + lo;
+            x.qa = (__builtin_amdgcn_ubfe(x.en.x, 16, 15) << 4) + lo;
+        };
+        // One general step: `cur` holds step t (entry, addresses, rows); `nxt.en` holds
+        // entry t+1.  Leaves `nxt` complete for step t+1 and cur.en = entry t+2.
+        // Two register sets alternate roles, so the loop is unrolled by two and nothing
+        // is copied between iterations.
+        auto step = [&](StepRegs& cur, StepRegs& nxt, const uint2* eptr, const int e2) {
+            const float r = __builtin_bit_cast(float, cur.en.y);
+            set_addr(nxt);
+            const float4 pn = lds_ld(lr_, nxt.pa);
+            const float4 qn = lds_ld(lr_, nxt.qa);
+            cur.en = eptr[e2];
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
+            const float dot = group_allreduce<L>(chunk_dot(cur.p, cur.q));
+            const float err = r - dot;
+            if constexpr (TRAIN) {
+                const float sc = lr * err;
+                const float4 p2 = axpy_row(sc, cur.q, c, cur.p);
+                const float4 q2 = axpy_row(sc, cur.p, c, cur.q);
+                lds_st(lr_, cur.pa, p2);
+                lds_st(lr_, cur.qa, q2);
+                const bool fwd = (int)nxt.en.x < 0;
+                nxt.q.x = fwd ? q2.x : qn.x;
+                nxt.q.y = fwd ? q2.y : qn.y;
+                nxt.q.z = fwd ? q2.z : qn.z;
+                nxt.q.w = fwd ? q2.w : qn.w;
+            } else {
+                acc += (double)err * (double)err;
+                nxt.q = qn;
             }
-            if (t < n) step(A, B, eptr, 2 * G);
-        }
-        if (nr > 0) {
-            const uint2* eptr = ebase + (size_t)n * G;
-            StepRegs A, B;
-            A.en = eptr[0];
-            B.en = eptr[G];
-            // every run entry of a slot carries the slot's item address
-            const unsigned rqa = (__builtin_amdgcn_ubfe(A.en.x, 16, 15) << 4) + laneoff;
-            A.pa = ((A.en.x & 0xFFFFu) << 4) + laneoff;
-            rq = lds_ld(lrows, rqa);
-            A.p = lds_ld(lrows, A.pa);
-            int t = 0;
-            for (; t + 1 < nr; t += 2, eptr += 2 * G) {
-                run_step(A, B, eptr, 2 * G);
-                run_step(B, A, eptr, 3 * G);
+            nxt.p = pn;
+        };
+        // Run step: the slot's q row is resident in `rq` for the whole run (no q load, no
+        // select, no q store); idle slots are flagged.
+        float4 rq;
+        auto run_step = [&](StepRegs& cur, StepRegs& nxt, const uint2* eptr, const int e2) {
+            const float r = __builtin_bit_cast(float, cur.en.y);
+            const bool active = (int)cur.en.x >= 0;
+            nxt.pa = ((nxt.en.x & 0xFFFFu) << 4) + lo;
+            const float4 pn = lds_ld(lr_, nxt.pa);
+            cur.en = eptr[e2];
+            const float dot = group_allreduce<L>(chunk_dot(cur.p, rq));
+            const float err = r - dot;
+            if constexpr (TRAIN) {
+                // idle slot: s = 0 and c = 1 leave the resident row bit-identical
+                // (fma(0, p, 1*q) == q) and rewrite zeros to the all-zero p row.
+                const float sc = active ? lr * err : 0.0f;
+                const float ce = active ? c : 1.0f;
+                const float4 p2 = axpy_row(sc, rq, ce, cur.p);
+                rq = axpy_row(sc, cur.p, ce, rq);
+                lds_st(lr_, cur.pa, p2);
+            } else {
+                acc += (double)err * (double)err;  // idle: p row and r are zero, err == 0
             }
-            if (t < nr) run_step(A, B, eptr, 2 * G);
-            if constexpr (TRAIN) lds_st(lrows, rqa, rq);
+            nxt.p = pn;
+        };
+        for (int s = 0; s < W; ++s) {
+            const uint2 sd = lsub[s * W + wave];
+            const int nall = __builtin_amdgcn_readfirstlane((int)sd.y);
+            const int n = nall & 0xFFFF;  // general steps
+            const int nr = nall >> 16;    // run steps, stored after the general ones
+            // entries of this wave's sub-cell; the host pads every cell with two idle
+            // steps, so reading entries t+1 and t+2 past the end stays inside the image
+            const uint2* ebase = lent + (size_t)__builtin_amdgcn_readfirstlane((int)sd.x) * G + g;
+            if (n > 0) {
+                const uint2* eptr = ebase;
+                StepRegs A, B;
+                A.en = eptr[0];
+                B.en = eptr[G];
+                set_addr(A);
+                A.p = lds_ld(lr_, A.pa);
+                A.q = lds_ld(lr_, A.qa);
+                int t = 0;
+                for (; t + 1 < n; t += 2, eptr += 2 * G) {
+                    step(A, B, eptr, 2 * G);
+                    step(B, A, eptr, 3 * G);
+                }
+                if (t < n) step(A, B, eptr, 2 * G);
+            }
+            if (nr > 0) {
+                const uint2* eptr = ebase + (size_t)n * G;
+                StepRegs A, B;
+                A.en = eptr[0];
+                B.en = eptr[G];
+                // every run entry of a slot carries the slot's item address
+                const unsigned rqa = (__builtin_amdgcn_ubfe(A.en.x, 16, 15) << 4) + lo;
+                A.pa = ((A.en.x & 0xFFFFu) << 4) + lo;
+                rq = lds_ld(lr_, rqa);
+                A.p = lds_ld(lr_, A.pa);
+                int t = 0;
+                for (; t + 1 < nr; t += 2, eptr += 2 * G) {
+                    run_step(A, B, eptr, 2 * G);
+                    run_step(B, A, eptr, 3 * G);
+                }
+                if (t < nr) run_step(A, B, eptr, 2 * G);
+                if constexpr (TRAIN) lds_st(lr_, rqa, rq);
+            }
+            if constexpr (TRAIN) __syncthreads();
         }
-        if constexpr (TRAIN) __syncthreads();
     }
+};
+
+// One workgroup = one cell, one launch = one round.  TRAIN: round `rd` runs cells
+// (b, (b + rd) % B).  !TRAIN: blockIdx.x is the cell index, no writes, SSE out.
+template <int L, int W, bool TRAIN, bool DIAG = false>
+__global__ void __launch_bounds__(64 * W)
+cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __restrict__ cells,
+            const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs,
+            const Entry* __restrict__ entries, const int B, const int rd, const float lr,
+            const float c, double* __restrict__ sse_partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Cell<L, W> cx;
+    cx.init_thread();
+    const int cell = TRAIN ? (int)blockIdx.x * B + ((int)blockIdx.x + rd) % B : (int)blockIdx.x;
+    const CellDesc cd = cells[cell];
+    unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0, real0 = 0;
+    if constexpr (DIAG) {
+        stamp0 = __builtin_amdgcn_s_memtime();
+        real0 = __builtin_amdgcn_s_memrealtime();
+    }
+    cx.bind(cd, smem);
+    if (cx.nrows == 0) {  // uniform over the workgroup
+        if (!TRAIN && cx.tid == 0) sse_partial[cell] = 0.0;
+        return;
+    }
+    cx.stage_schedule(cd, cell, rows, subs, entries);
+    __syncthreads();
+    cx.gather(P, Q, 0, cx.nrows);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (DIAG) stamp1 = __builtin_amdgcn_s_memtime();
+
+    double acc = 0.0;
+    cx.template apply<TRAIN>(lr, c, acc);
 
     if constexpr (DIAG) stamp2 = __builtin_amdgcn_s_memtime();
     if constexpr (TRAIN) {
-        // ---- scatter: LDS -> rows ----------------------------------------------
-        constexpr int UNR = 4;
-        int s = wave * G + g;
-        for (; s + (UNR - 1) * W * G < nrows; s += UNR * W * G) {
-            uint32_t rid[UNR];
-            float4 v[UNR];
-#pragma unroll
-            for (int x = 0; x < UNR; ++x) {
-                rid[x] = lids[s + x * W * G];
-                v[x] = lds_ld(lrows, (unsigned)((s + x * W * G) * ROWB) + laneoff);
-            }
-#pragma unroll
-            for (int x = 0; x < UNR; ++x) {
-                const int sx = s + x * W * G;
-                float* dst = (sx < nu ? P : Q) + (size_t)rid[x] * KP + lig * 4;
-                *reinterpret_cast<float4*>(dst) = v[x];
-            }
-        }
-        for (; s < nrows; s += W * G) {
-            const uint32_t rid = lids[s];
-            float* dst = (s < nu ? P : Q) + (size_t)rid * KP + lig * 4;
-            *reinterpret_cast<float4*>(dst) = lds_ld(lrows, (unsigned)(s * ROWB) + laneoff);
-        }
+        cx.template scatter<false>(P, Q, 0, cx.nrows);
         if constexpr (DIAG) {
-            // diagnostic build only: phase stamps of this workgroup (shader clock ticks)
+            // diagnostic build only: phase stamps of this workgroup
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
-            if (tid == 0) {
-                unsigned long long* o = reinterpret_cast<unsigned long long*>(sse_partial) + (size_t)blockIdx.x * 4;
+            const unsigned long long real3 = __builtin_amdgcn_s_memrealtime();
+            if (cx.tid == 0) {
+                unsigned long long* o = reinterpret_cast<unsigned long long*>(sse_partial) + (size_t)blockIdx.x * 6;
                 o[0] = stamp0;
                 o[1] = stamp1;
                 o[2] = stamp2;
                 o[3] = stamp3;
+                o[4] = real0;  // 100 MHz constant clock, common to all XCDs
+                o[5] = real3;
             }
         }
     } else {
         // ---- deterministic sum of squared errors --------------------------------
         // every lane of a group carries the group's sum: keep one copy, then a
         // fixed butterfly over the wave, then waves in index order.
-        double v = lig == 0 ? acc : 0.0;
+        double v = cx.lig == 0 ? acc : 0.0;
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
         __syncthreads();  // everyone is done reading lsub/lent before they are reused
-        double* wsum = reinterpret_cast<double*>(lent);
-        if (lane == 0) wsum[wave] = v;
+        double* wsum = reinterpret_cast<double*>(cx.lent);
+        if (cx.lane == 0) wsum[cx.wave] = v;
         __syncthreads();
-        if (tid == 0) {
+        if (cx.tid == 0) {
             double t = 0.0;
             for (int w = 0; w < W; ++w) t += wsum[w];
             sse_partial[cell] = t;
+        }
+    }
+}
+
+// ---- persistent epoch kernel -----------------------------------------------------
+// One launch = n_rounds consecutive rounds (an epoch is B rounds).  Workgroup x owns
+// user blocks x, x + NP, ... for the whole launch: their P rows are only ever touched
+// by this workgroup (this CU), so they need no inter-workgroup protocol.  Item tiles
+// move: tile (b + rd) % B is trained by block b in round rd and by block b - 1 in
+// round rd + 1, i.e. block b waits for block b + 1 -- a ring hand-off between
+// workgroups inside the GPU, the same shape as the DSGD ring between GPUs.
+//   producer: q rows stored write-through (sc1) -> every wave s_waitcnt vmcnt(0) ->
+//             workgroup barrier -> one lane stores done[b] = R + 1 (relaxed, agent scope);
+//   consumer: one lane polls done[b + 1] >= R (relaxed, agent scope, s_sleep) -> agent
+//             acquire fence -> s_waitcnt vmcnt(0) -> workgroup barrier -> plain loads.
+// (cdna_hip_programming.md Guideline 16, form R1.)  While it waits, a workgroup has
+// already staged the next cell's schedule and gathered its own P rows.  All NP
+// workgroups must be co-resident (the host sizes NP from the occupancy query); every
+// spin is bounded and raises *abort_word instead of hanging.
+constexpr int kFlagStride = 32;  // one done[] word per 128-byte line
+
+template <int L, int W>
+__global__ void __launch_bounds__(64 * W)
+epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __restrict__ cells,
+             const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs,
+             const Entry* __restrict__ entries, const int B, const int n_rounds, const float lr,
+             const float c, unsigned* __restrict__ done, unsigned* __restrict__ abort_word) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using gu32 = __attribute__((address_space(1))) unsigned;
+    volatile unsigned* const ctl = reinterpret_cast<volatile unsigned*>(smem);  // [0] = abort broadcast
+    Cell<L, W> cx;
+    cx.init_thread();
+    const int NP = (int)gridDim.x;
+    if (cx.tid == 0) ctl[0] = 0;
+    __syncthreads();
+    for (int R = 0; R < n_rounds; ++R) {
+        const int rd = R % B;
+        for (int b = (int)blockIdx.x; b < B; b += NP) {
+            const int cell = b * B + (b + rd) % B;
+            const CellDesc cd = cells[cell];
+            cx.bind(cd, smem);
+            const bool work = cx.nrows != 0;  // uniform over the workgroup
+            if (work) {
+                cx.stage_schedule(cd, cell, rows, subs, entries);
+                __syncthreads();
+                cx.gather(P, Q, 0, cx.nu);  // own rows: no dependency on other workgroups
+            }
+            if (R > 0) {
+                // wait until block b + 1 has finished round R - 1 (it held our tile)
+                if (cx.tid == 0) {
+                    gu32* flag = (gu32*)(done + (size_t)((b + 1) % B) * kFlagStride);
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)R) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if ((++spins & 255u) == 0u) {
+                            if (__hip_atomic_load((gu32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                                spins > (1u << 22)) {
+                                __hip_atomic_store((gu32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ctl[0] = 1;
+                                break;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            __syncthreads();
+            if (ctl[0] != 0) return;  // uniform: some workgroup timed out
+            if (work) {
+                cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                double acc = 0.0;
+                cx.template apply<true>(lr, c, acc);  // ends with a workgroup barrier
+                cx.template scatter<true>(P, Q, cx.nu, cx.nrows);
+            }
+            // publish the tile: every storing wave drains, then one lane signals
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (cx.tid == 0)
+                __hip_atomic_store((gu32*)(done + (size_t)b * kFlagStride), (unsigned)(R + 1), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (work) cx.template scatter<false>(P, Q, 0, cx.nu);
+            // this workgroup re-reads these P rows in a later round: drain the stores and
+            // finish the LDS reads before the image is overwritten
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
     }
 }
@@ -377,6 +507,46 @@ hipError_t launch_cell_LW(bool train, const CellLaunch& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int L, int W>
+hipError_t epoch_LW(int what, const CellLaunch& a, int n_rounds, unsigned* done, unsigned* abort_word, int* out,
+                    hipStream_t st) {
+    const void* fn = (const void*)epoch_kernel<L, W>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
+    if (e != hipSuccess) return e;
+    if (what == 0) {  // occupancy query: workgroups per CU
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, 64 * W, (size_t)a.lds_bytes);
+    }
+    hipLaunchKernelGGL((epoch_kernel<L, W>), dim3((unsigned)a.grid), dim3(64 * W), (size_t)a.lds_bytes, st, a.P, a.Q,
+                       a.cells, a.rows, a.subs, a.entries, a.B, n_rounds, a.lr, a.c, done, abort_word);
+    return hipGetLastError();
+}
+
+template <int L>
+hipError_t epoch_L(int what, int W, const CellLaunch& a, int n_rounds, unsigned* done, unsigned* abort_word, int* out,
+                   hipStream_t st) {
+    switch (W) {
+        case 1: return epoch_LW<L, 1>(what, a, n_rounds, done, abort_word, out, st);
+        case 2: return epoch_LW<L, 2>(what, a, n_rounds, done, abort_word, out, st);
+        case 4: return epoch_LW<L, 4>(what, a, n_rounds, done, abort_word, out, st);
+        case 8: return epoch_LW<L, 8>(what, a, n_rounds, done, abort_word, out, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t epoch_dispatch(int what, int L, int W, const CellLaunch& a, int n_rounds, unsigned* done,
+                          unsigned* abort_word, int* out, hipStream_t st) {
+    switch (L) {
+        case 1: return epoch_L<1>(what, W, a, n_rounds, done, abort_word, out, st);
+        case 2: return epoch_L<2>(what, W, a, n_rounds, done, abort_word, out, st);
+        case 4: return epoch_L<4>(what, W, a, n_rounds, done, abort_word, out, st);
+        case 8: return epoch_L<8>(what, W, a, n_rounds, done, abort_word, out, st);
+        case 16: return epoch_L<16>(what, W, a, n_rounds, done, abort_word, out, st);
+        case 32: return epoch_L<32>(what, W, a, n_rounds, done, abort_word, out, st);
+        case 64: return epoch_L<64>(what, W, a, n_rounds, done, abort_word, out, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 template <int L>
 hipError_t launch_cell_L(bool train, int W, const CellLaunch& a, hipStream_t st) {
     switch (W) {
@@ -401,6 +571,15 @@ hipError_t launch_cell(bool train, int L, int W, const CellLaunch& a, hipStream_
         case 64: return launch_cell_L<64>(train, W, a, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t epoch_blocks_per_cu(int L, int W, const CellLaunch& a, int* blocks_per_cu) {
+    return epoch_dispatch(0, L, W, a, 0, nullptr, nullptr, blocks_per_cu, nullptr);
+}
+
+hipError_t launch_epoch_persistent(int L, int W, const CellLaunch& a, int n_rounds, unsigned* done,
+                                   unsigned* abort_word, hipStream_t st) {
+    return epoch_dispatch(1, L, W, a, n_rounds, done, abort_word, nullptr, st);
 }
 
 hipError_t launch_reduce_sse(const double* partial, int64_t n, double* out, hipStream_t st) {

@@ -28,6 +28,13 @@ struct CellLaunch {
 
 // One training round (train = true) or the SSE pass over every cell.
 hipError_t launch_cell(bool train, int L, int W, const CellLaunch& a, hipStream_t st);
+// Persistent epoch kernel: a.grid workgroups (all must be co-resident: at most
+// blocks_per_cu x CUs) run n_rounds rounds; `done` holds B words spaced kDoneStride
+// apart (zeroed by the caller before every launch), `abort_word` one word.
+constexpr int kDoneStride = 32;
+hipError_t epoch_blocks_per_cu(int L, int W, const CellLaunch& a, int* blocks_per_cu);
+hipError_t launch_epoch_persistent(int L, int W, const CellLaunch& a, int n_rounds, unsigned* done,
+                                   unsigned* abort_word, hipStream_t st);
 hipError_t launch_reduce_sse(const double* partial, int64_t n, double* out, hipStream_t st);
 hipError_t launch_predict(int L, const float* P, const float* Q, const int32_t* u, const int32_t* i,
                           float* out, int64_t n, hipStream_t st);

@@ -26,8 +26,8 @@ Geometry geometry_for_k(int k) {
 
 // LDS image of a cell: rows | 2G all-zero rows | step entries | sub-cell table | row ids
 int64_t lds_bytes_for(const Geometry& geo, int W, int nrows, int64_t n_steps) {
-    int64_t b = (int64_t)(nrows + 2 * geo.G) * geo.rowbytes + n_steps * geo.G * 8 + (int64_t)W * W * 8 +
-                (int64_t)nrows * 4;
+    int64_t b = 16 /* control block */ + (int64_t)(nrows + 2 * geo.G) * geo.rowbytes + n_steps * geo.G * 8 +
+                (int64_t)W * W * 8 + (int64_t)nrows * 4;
     return (b + 15) & ~(int64_t)15;
 }
 

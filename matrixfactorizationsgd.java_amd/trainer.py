@@ -184,9 +184,10 @@ class MatrixFactorizationSGD:
         return cells, rows, subs, entries
 
     def debug_round_stamps(self, rnd):
-        """[blocks, 4] shader-clock stamps of one training round (diagnostic)."""
+        """[blocks, 6] stamps of one training round (diagnostic): 4 shader-clock phase
+        stamps, then the 100 MHz constant clock at start and end."""
         info = self.schedule_info()
-        out = np.zeros((info["blocks"], 4), np.uint64)
+        out = np.zeros((info["blocks"], 6), np.uint64)
         self._check(self._lib.mfsgd_debug_round_stamps(self._handle(), 0, int(rnd), _p(out, C.c_uint64)))
         return out
 

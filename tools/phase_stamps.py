@@ -16,14 +16,18 @@ m.fit(1, rmse=False)
 info = m.schedule_info()
 print({k: info[k] for k in ("blocks", "waves", "slots", "lds_bytes", "total_steps", "sum_round_steps", "max_cell_steps")})
 acc = []
+import time
+for _ in range(3): m.fit(1, rmse=False)
 for rd in range(0, info["blocks"], max(1, info["blocks"] // 16)):
     s = m.debug_round_stamps(rd).astype(np.int64)
-    t0 = s[:, 0].min()
     g, st, sc = s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2]
-    tot = s[:, 3].max() - t0
-    slow = np.argmax(s[:, 3])
-    acc.append((tot, g.mean(), st.mean(), sc.mean(), g[slow], st[slow], sc[slow], (s[:, 0] - t0).max()))
-a = np.array(acc, float)
-print("clock ticks (100 MHz s_memtime? see guide: shader clock) per round, mean over sampled rounds:")
-print("  round span %.0f | mean WG: gather %.0f steps %.0f scatter %.0f | slowest WG: gather %.0f steps %.0f scatter %.0f | last WG start +%.0f"
-      % tuple(a.mean(axis=0)))
+    dur_cyc = s[:, 3] - s[:, 0]
+    dur_real = (s[:, 5] - s[:, 4]) * 10.0  # ns
+    clk = dur_cyc / np.maximum(dur_real, 1)  # GHz
+    span_ns = (s[:, 5].max() - s[:, 4].min()) * 10.0
+    start_spread_ns = (s[:, 4].max() - s[:, 4].min()) * 10.0
+    slow = np.argmax(s[:, 5])
+    acc.append((g.mean(), st.mean(), sc.mean(), g[slow], st[slow], sc[slow], np.median(clk), span_ns, start_spread_ns, dur_real.mean(), dur_real.max()))
+a = np.array(acc, float).mean(axis=0)
+print("mean WG cycles: gather %.0f steps %.0f scatter %.0f | last-finishing WG: gather %.0f steps %.0f scatter %.0f" % tuple(a[:6]))
+print("shader clock %.2f GHz | first WG start -> last WG end %.2f us | WG start spread %.2f us | WG lifetime mean %.2f us max %.2f us" % (a[6], a[7]/1e3, a[8]/1e3, a[9]/1e3, a[10]/1e3))
