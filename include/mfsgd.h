@@ -155,7 +155,9 @@ int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cell
 /* Diagnostic (not part of the Java surface): runs training round `round` once with
  * phase stamps; out receives blocks x 6 values per workgroup: shader-clock at
  * start, after gather, after the rating steps, after scatter, then the 100 MHz
- * constant clock at start and at end.  It DOES apply
+ * constant clock at start and at end; after those blocks x 6 words follow
+ * blocks x W x W x 4 words: per (wave, sub-round) cycles in the general loop,
+ * cycles in the run loop, general steps, run steps.  It DOES apply
  * that round's updates.  Single-partition handles only.                        */
 int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint64_t* out);
 

@@ -721,12 +721,19 @@ int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint6
     if (rc) return rc;
     Part& p = h->parts[0];
     if (round < 0 || round >= p.sched.B) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_round_stamps: bad round");
-    if ((size_t)p.sched.B * 6 * sizeof(uint64_t) > p.d_sse_partial.bytes) return fail(h, MFSGD_ERR_STATE, "debug_round_stamps: buffer too small");
+    const size_t words = (size_t)p.sched.B * (6 + (size_t)p.sched.W * p.sched.W * 4);
+    if (words * sizeof(uint64_t) > p.d_sse_partial.bytes) {
+        int rc2 = dev_alloc(h, p.d_sse_partial, words * sizeof(uint64_t));
+        if (rc2) return rc2;
+    }
     CellLaunch a = make_launch(h, p, static_cast<float*>(h->dQ.p));
     a.rd = round;
     a.diag = true;
+    
+    HIPCHK(h, hipMemsetAsync(p.d_sse_partial.p, 0, words * sizeof(uint64_t), h->stream));
+    a.sse_partial = static_cast<double*>(p.d_sse_partial.p);
     HIPCHK(h, launch_cell(true, h->geo.L, p.sched.W, a, h->stream));
-    HIPCHK(h, hipMemcpyAsync(out, p.d_sse_partial.p, (size_t)p.sched.B * 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out, p.d_sse_partial.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return MFSGD_OK;
 }

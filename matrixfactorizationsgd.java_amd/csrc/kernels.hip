@@ -24,6 +24,11 @@
 
 #pragma clang fp contract(off)
 
+// Timing-only ablations of the run loop (tools/exp.sh); results are wrong when != 0.
+#ifndef MFSGD_EXP
+#define MFSGD_EXP 0
+#endif
+
 namespace mfsgd {
 
 namespace {
@@ -179,8 +184,9 @@ struct Cell {
         float4 p, q;
     };
 
-    template <bool TRAIN>
-    __device__ __forceinline__ void apply(const float lr, const float c, double& acc) {
+    template <bool TRAIN, bool TIMED = false>
+    __device__ __forceinline__ void apply(const float lr, const float c, double& acc,
+                                          unsigned long long* timers = nullptr) {
         unsigned char* const lr_ = lrows;
         const unsigned lo = laneoff;
         auto set_addr = [&](StepRegs& x) {
@@ -192,6 +198,8 @@ struct Cell {
         // Two register sets alternate roles, so the loop is unrolled by two and nothing
         // is copied between iterations.
         auto step = [&](StepRegs& cur, StepRegs& nxt, const uint2* eptr, const int e2) {
+            __builtin_amdgcn_sched_barrier(0);  // the prefetch below must not climb into the previous step
+            asm volatile("" : "+v"(nxt.en.x));   // ... nor its address arithmetic (no instruction emitted)
             const float r = __builtin_bit_cast(float, cur.en.y);
             set_addr(nxt);
             const float4 pn = lds_ld(lr_, nxt.pa);
@@ -221,21 +229,44 @@ struct Cell {
         // select, no q store); idle slots are flagged.
         float4 rq;
         auto run_step = [&](StepRegs& cur, StepRegs& nxt, const uint2* eptr, const int e2) {
+            __builtin_amdgcn_sched_barrier(0);  // the prefetch below must not climb into the previous step
+            asm volatile("" : "+v"(nxt.en.x));   // ... nor its address arithmetic (no instruction emitted)
             const float r = __builtin_bit_cast(float, cur.en.y);
             const bool active = (int)cur.en.x >= 0;
             nxt.pa = ((nxt.en.x & 0xFFFFu) << 4) + lo;
+#if MFSGD_EXP == 2
+            const float4 pn = cur.p;
+            asm volatile("" ::"v"(nxt.pa), "v"(eptr));
+#else
             const float4 pn = lds_ld(lr_, nxt.pa);
             cur.en = eptr[e2];
+#endif
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
+#if MFSGD_EXP == 3
+            const float dot = chunk_dot(cur.p, rq);
+#else
             const float dot = group_allreduce<L>(chunk_dot(cur.p, rq));
+#endif
             const float err = r - dot;
             if constexpr (TRAIN) {
-                // idle slot: s = 0 and c = 1 leave the resident row bit-identical
+                // idle slot: s == 0 and c = 1 leave the resident row bit-identical
                 // (fma(0, p, 1*q) == q) and rewrite zeros to the all-zero p row.
-                const float sc = active ? lr * err : 0.0f;
+                // (an idle slot has p = 0 and r = 0, so err and s are exactly 0 already;
+                // only c needs the select, and that is off the dependent chain)
+                const float sc = lr * err;
+#if MFSGD_EXP == 4
+                const float ce = c;
+                asm volatile("" ::"s"(active));
+#else
                 const float ce = active ? c : 1.0f;
+#endif
                 const float4 p2 = axpy_row(sc, rq, ce, cur.p);
                 rq = axpy_row(sc, cur.p, ce, rq);
+#if MFSGD_EXP == 1
+                asm volatile("" ::"v"(p2.x), "v"(p2.y), "v"(p2.z), "v"(p2.w), "v"(cur.pa));
+#else
                 lds_st(lr_, cur.pa, p2);
+#endif
             } else {
                 acc += (double)err * (double)err;  // idle: p row and r are zero, err == 0
             }
@@ -249,6 +280,8 @@ struct Cell {
             // entries of this wave's sub-cell; the host pads every cell with two idle
             // steps, so reading entries t+1 and t+2 past the end stays inside the image
             const uint2* ebase = lent + (size_t)__builtin_amdgcn_readfirstlane((int)sd.x) * G + g;
+            unsigned long long tm0 = 0, tm1 = 0, tm2 = 0;
+            if constexpr (TIMED) tm0 = __builtin_amdgcn_s_memtime();
             if (n > 0) {
                 const uint2* eptr = ebase;
                 StepRegs A, B;
@@ -264,6 +297,7 @@ struct Cell {
                 }
                 if (t < n) step(A, B, eptr, 2 * G);
             }
+            if constexpr (TIMED) tm1 = __builtin_amdgcn_s_memtime();
             if (nr > 0) {
                 const uint2* eptr = ebase + (size_t)n * G;
                 StepRegs A, B;
@@ -281,6 +315,16 @@ struct Cell {
                 }
                 if (t < nr) run_step(A, B, eptr, 2 * G);
                 if constexpr (TRAIN) lds_st(lr_, rqa, rq);
+            }
+            if constexpr (TIMED) {
+                tm2 = __builtin_amdgcn_s_memtime();
+                if (lane == 0) {  // [wave][sub-round] -> {general cycles, run cycles, general steps, run steps}
+                    unsigned long long* o = timers + ((size_t)wave * W + s) * 4;
+                    o[0] = tm1 - tm0;
+                    o[1] = tm2 - tm1;
+                    o[2] = (unsigned long long)n;
+                    o[3] = (unsigned long long)nr;
+                }
             }
             if constexpr (TRAIN) __syncthreads();
         }
@@ -318,7 +362,11 @@ cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __rest
     if constexpr (DIAG) stamp1 = __builtin_amdgcn_s_memtime();
 
     double acc = 0.0;
-    cx.template apply<TRAIN>(lr, c, acc);
+    if constexpr (DIAG)
+        cx.template apply<TRAIN, true>(lr, c, acc, reinterpret_cast<unsigned long long*>(sse_partial) +
+                                                       (size_t)gridDim.x * 6 + (size_t)blockIdx.x * W * W * 4);
+    else
+        cx.template apply<TRAIN>(lr, c, acc);
 
     if constexpr (DIAG) stamp2 = __builtin_amdgcn_s_memtime();
     if constexpr (TRAIN) {

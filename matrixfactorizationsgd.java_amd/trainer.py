@@ -187,9 +187,11 @@ class MatrixFactorizationSGD:
         """[blocks, 6] stamps of one training round (diagnostic): 4 shader-clock phase
         stamps, then the 100 MHz constant clock at start and end."""
         info = self.schedule_info()
-        out = np.zeros((info["blocks"], 6), np.uint64)
+        B, W = info["blocks"], info["waves"]
+        out = np.zeros(B * (6 + W * W * 4), np.uint64)
         self._check(self._lib.mfsgd_debug_round_stamps(self._handle(), 0, int(rnd), _p(out, C.c_uint64)))
-        return out
+        self.last_loop_timers = out[B * 6:].reshape(B, W, W, 4)  # [block, wave, sub-round, (gen cyc, run cyc, gen steps, run steps)]
+        return out[:B * 6].reshape(B, 6)
 
     # -- DSGD building blocks (n_parts > 1); see dsgd.py ---------------------------
     def part_rows(self, part):
