@@ -8,8 +8,9 @@ P[u] and Q[i]) over every rating of the workload.  N = 1 runs BASELINE.json's
 configs[2] -- the configuration its metric is quoted on: MovieLens-20M shape
 (138,493 x 26,744, 20M ratings), k = 64, fp32 -- on synthetic data.  N > 1 is
 DSGD (weak scaling): every rank holds the same number of users and ratings as
-the N = 1 run, the item factors are cut into N blocks that rotate between the
-ranks over RCCL send/recv; value = ratings processed by all ranks / max-over-
+the N = 1 run and the item catalogue is N times larger (users, items and ratings
+all scale with N); the item factors are cut into N blocks that rotate between
+the ranks over RCCL send/recv; value = ratings processed by all ranks / max-over-
 ranks time.  Ratings, schedules and factors are resident in HBM before the
 timed region; the timed region contains the training passes only (no RMSE
 pass, no host<->device copies).
@@ -99,6 +100,8 @@ def main():
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo "
+                    "(rehearsal: several ranks on one GPU, ring staged through host memory)")
     ap.add_argument("--round-launch", action="store_true", help="one kernel per round instead of the persistent epoch kernel")
     args = ap.parse_args()
 
@@ -117,17 +120,25 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libmfsgd has no CPU path")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- workload (rank-specific users and ratings; items are shared) -----------
     t0 = time.time()
-    w = synth.workload(args.workload, args.scale, seed_offset=1000 * rank)
+    # weak scaling: every rank brings its own 138,493 users and 20 M ratings, and the item
+    # catalogue grows with the rank count (N x 26,744 items), so that the longest per-row
+    # dependency chain a rank has to serialise stays what it is at N = 1
+    w = synth.workload(args.workload, args.scale, seed_offset=1000 * rank, item_mult=world)
     if rank == 0:
         log(f"generated {w['nnz']} ratings ({w['U']} x {w['I']}, {w['dist']}) in {time.time() - t0:.1f} s")
     k, nnz = w["k"], w["nnz"]
@@ -201,8 +212,8 @@ def main():
     achieved_gbs = units_per_launch * bytes_per_update / avg_launch_s / 1e9
     roofline = {
         "bound": "hbm",
-        "kernel": ("mfsgd::epoch_kernel<L,W> (persistent: one launch per epoch)" if launches == args.steps
-                   else "mfsgd::cell_kernel<L,W,train> (one launch per round)"),
+        "kernel": ("mfsgd::cell_kernel<L,W,train> (one launch per round)" if args.round_launch
+                   else "mfsgd::epoch_kernel<L,W> (persistent: one launch per epoch and item partition)"),
         "achieved": achieved_gbs,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -231,7 +242,7 @@ def main():
             "users_per_gpu": w["U"], "items": w["I"], "nnz_per_gpu": nnz, "k": k,
             "lr": LR, "lambda": LAM, "scale": args.scale,
             "blocks": infos[0]["blocks"], "waves": infos[0]["waves"],
-            "parallelism": "single" if world == 1 else f"dsgd{world}",
+            "parallelism": "single" if world == 1 else f"dsgd{world}" + ("-gloo-rehearsal" if args.backend == "gloo" else ""),
         },
         "rmse_before": rmse0,
         "rmse_after": rmse1,

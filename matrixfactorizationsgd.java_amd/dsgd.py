@@ -68,18 +68,32 @@ class TorchDistRing:
             recv_block.copy_(send_block)
             return
         d = self.dist
+        if send_block.is_cuda and d.get_backend() == "gloo":
+            # rehearsal mode (several ranks sharing one GPU, where RCCL cannot run):
+            # stage through host memory.  The production path is the branch below.
+            hs, hr = send_block.cpu(), recv_block.cpu()
+            for req in d.batch_isend_irecv([d.P2POp(d.isend, hs, (self.rank - 1) % self.world),
+                                            d.P2POp(d.irecv, hr, (self.rank + 1) % self.world)]):
+                req.wait()
+            recv_block.copy_(hr)
+            return
         ops = [d.P2POp(d.isend, send_block, (self.rank - 1) % self.world),
                d.P2POp(d.irecv, recv_block, (self.rank + 1) % self.world)]
         for req in d.batch_isend_irecv(ops):
             req.wait()
 
+    def _dev(self, device):
+        return "cpu" if self.world > 1 and self.dist.get_backend() == "gloo" else device
+
     def sum_f64(self, values, torch, device):
+        device = self._dev(device)
         t = torch.tensor(values, dtype=torch.float64, device=device)
         if self.world > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().tolist()
 
     def max_f64(self, value, torch, device):
+        device = self._dev(device)
         t = torch.tensor([value], dtype=torch.float64, device=device)
         if self.world > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)

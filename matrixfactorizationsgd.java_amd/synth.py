@@ -103,12 +103,17 @@ def make_ratings(U, I, nnz, k, dist="uniform", seed=0, k_true=16, noise=0.1, **k
     return u, i, r
 
 
-def workload(name, scale=1.0, seed_offset=0):
+def workload(name, scale=1.0, seed_offset=0, item_mult=1):
     """Ratings of a named workload; scale < 1 shrinks U, I and nnz together
     (for parity tests at sizes the oracle finishes in seconds); seed_offset
-    gives each DSGD rank its own users and ratings."""
+    gives each DSGD rank its own users and ratings; item_mult widens the item
+    catalogue (weak scaling over N GPUs: N times the items, same ratings per rank)."""
     w = dict(WORKLOADS[name])
     w["seed"] = w["seed"] + seed_offset
+    if item_mult != 1:
+        w["I"] = w["I"] * item_mult
+        if "q_item" in w:
+            w["q_item"] = w["q_item"] * item_mult
     if scale != 1.0:
         if w["dist"] == "dense":
             w["U"] = max(2, int(w["U"] * math.sqrt(scale)))
