@@ -146,7 +146,8 @@ int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t
  * partition, so that tests can replay the kernel's exact LDS access order on the CPU.
  * cells: n_cells x 4 words {row_off, ent_off, n_steps, nu | ni << 16};
  * subs: n_subs x 2 words {off, general steps | run steps << 16};
- * entries: n_entries x 2 words {p addr | q addr << 16 | flag << 31 (16-byte units), rating bits}. */
+ * entries: n_entries x 4 words {p addr | q addr << 16 | flag << 31 (16-byte units), rating bits,
+ * bits of lr*rating, bits of the slot's decay factor}.                                         */
 int mfsgd_debug_schedule_sizes(const mfsgd_handle* h, int32_t part, int64_t* n_cells, int64_t* n_rows,
                                int64_t* n_subs, int64_t* n_entries);
 int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cells, uint32_t* rows,

@@ -425,6 +425,8 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
         SchedParams prm;
         prm.U = h->cfg.n_users;
         prm.k = h->cfg.k;
+        prm.lr = h->cfg.lr;
+        prm.lambda = h->cfg.lambda;
         prm.B = h->cfg.blocks;
         prm.W = h->cfg.waves;
         prm.threads = h->cfg.host_threads;

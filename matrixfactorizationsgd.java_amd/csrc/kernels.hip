@@ -88,7 +88,7 @@ __device__ __forceinline__ void lds_st(unsigned char* base, unsigned off, const 
 // per-round kernel, the SSE pass and the persistent epoch kernel.
 //
 // LDS image (after a 16-byte control block):
-//   [rows: nrows x ROWB][2G zero rows][entries: n_steps x G x 8][subs: W*W x 8][row ids: nrows x 4]
+//   [rows: nrows x ROWB][2G zero rows][entries: n_steps x G x 16][subs: W*W x 8][row ids: nrows x 4]
 // rows: LDS slots [0, nu) hold p-side (user) rows, [nu, nrows) q-side (item) rows.
 template <int L, int W>
 struct Cell {
@@ -102,7 +102,7 @@ struct Cell {
     unsigned laneoff;
     int nu, nrows, n_steps;
     unsigned char* lrows;
-    uint2* lent;
+    uint4* lent;
     uint2* lsub;
     uint32_t* lids;
 
@@ -119,8 +119,8 @@ struct Cell {
         nrows = (int)cd.nu + (int)cd.ni;
         n_steps = (int)cd.n_steps;
         lrows = smem + CTL;
-        lent = reinterpret_cast<uint2*>(lrows + (size_t)(nrows + 2 * G) * ROWB);
-        lsub = lent + (size_t)n_steps * G;
+        lent = reinterpret_cast<uint4*>(lrows + (size_t)(nrows + 2 * G) * ROWB);
+        lsub = reinterpret_cast<uint2*>(lent + (size_t)n_steps * G);
         lids = reinterpret_cast<uint32_t*>(lsub + W * W);
     }
 
@@ -131,7 +131,7 @@ struct Cell {
                                                    const Entry* __restrict__ entries) {
         const uint32_t* const crow = rows + cd.row_off;
         for (int x = tid; x < nrows; x += NT) lids[x] = crow[x];
-        const uint2* gent = reinterpret_cast<const uint2*>(entries) + (size_t)cd.ent_off * G;
+        const uint4* gent = reinterpret_cast<const uint4*>(entries) + (size_t)cd.ent_off * G;
         const int ne = n_steps * G;
         for (int x = tid; x < ne; x += NT) lent[x] = gent[x];
         if (tid < W * W) lsub[tid] = reinterpret_cast<const uint2*>(subs)[(size_t)cell * W * W + tid];
@@ -179,7 +179,7 @@ struct Cell {
     // row read that early was not written in step t, except a q-side row in the same
     // lane slot, which is flagged and taken from registers instead.
     struct StepRegs {
-        uint2 en;  // entry: addresses | flag, rating
+        uint4 en;  // entry: addresses | flag, rating, lr*rating, decay factor
         unsigned pa, qa;
         float4 p, q;
     };
@@ -197,19 +197,18 @@ struct Cell {
         // entry t+1.  Leaves `nxt` complete for step t+1 and cur.en = entry t+2.
         // Two register sets alternate roles, so the loop is unrolled by two and nothing
         // is copied between iterations.
-        auto step = [&](StepRegs& cur, StepRegs& nxt, const uint2* eptr, const int e2) {
+        auto step = [&](StepRegs& cur, StepRegs& nxt, const uint4* eptr, const int e2) {
             __builtin_amdgcn_sched_barrier(0);  // the prefetch below must not climb into the previous step
             asm volatile("" : "+v"(nxt.en.x));   // ... nor its address arithmetic (no instruction emitted)
-            const float r = __builtin_bit_cast(float, cur.en.y);
+            const float r = __builtin_bit_cast(float, TRAIN ? cur.en.z : cur.en.y);  // lr*r when training
             set_addr(nxt);
             const float4 pn = lds_ld(lr_, nxt.pa);
             const float4 qn = lds_ld(lr_, nxt.qa);
             cur.en = eptr[e2];
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
             const float dot = group_allreduce<L>(chunk_dot(cur.p, cur.q));
-            const float err = r - dot;
             if constexpr (TRAIN) {
-                const float sc = lr * err;
+                const float sc = __builtin_fmaf(-lr, dot, r);  // lr*(r - dot): one dependent operation
                 const float4 p2 = axpy_row(sc, cur.q, c, cur.p);
                 const float4 q2 = axpy_row(sc, cur.p, c, cur.q);
                 lds_st(lr_, cur.pa, p2);
@@ -220,6 +219,7 @@ struct Cell {
                 nxt.q.z = fwd ? q2.z : qn.z;
                 nxt.q.w = fwd ? q2.w : qn.w;
             } else {
+                const float err = r - dot;
                 acc += (double)err * (double)err;
                 nxt.q = qn;
             }
@@ -228,46 +228,26 @@ struct Cell {
         // Run step: the slot's q row is resident in `rq` for the whole run (no q load, no
         // select, no q store); idle slots are flagged.
         float4 rq;
-        auto run_step = [&](StepRegs& cur, StepRegs& nxt, const uint2* eptr, const int e2) {
+        auto run_step = [&](StepRegs& cur, StepRegs& nxt, const uint4* eptr, const int e2) {
             __builtin_amdgcn_sched_barrier(0);  // the prefetch below must not climb into the previous step
             asm volatile("" : "+v"(nxt.en.x));   // ... nor its address arithmetic (no instruction emitted)
-            const float r = __builtin_bit_cast(float, cur.en.y);
-            const bool active = (int)cur.en.x >= 0;
+            const float r = __builtin_bit_cast(float, TRAIN ? cur.en.z : cur.en.y);
+            const float ce = __builtin_bit_cast(float, cur.en.w);
             nxt.pa = ((nxt.en.x & 0xFFFFu) << 4) + lo;
-#if MFSGD_EXP == 2
-            const float4 pn = cur.p;
-            asm volatile("" ::"v"(nxt.pa), "v"(eptr));
-#else
             const float4 pn = lds_ld(lr_, nxt.pa);
             cur.en = eptr[e2];
-#endif
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
-#if MFSGD_EXP == 3
-            const float dot = chunk_dot(cur.p, rq);
-#else
             const float dot = group_allreduce<L>(chunk_dot(cur.p, rq));
-#endif
-            const float err = r - dot;
             if constexpr (TRAIN) {
-                // idle slot: s == 0 and c = 1 leave the resident row bit-identical
-                // (fma(0, p, 1*q) == q) and rewrite zeros to the all-zero p row.
-                // (an idle slot has p = 0 and r = 0, so err and s are exactly 0 already;
-                // only c needs the select, and that is off the dependent chain)
-                const float sc = lr * err;
-#if MFSGD_EXP == 4
-                const float ce = c;
-                asm volatile("" ::"s"(active));
-#else
-                const float ce = active ? c : 1.0f;
-#endif
+                // idle slot: p = 0 and r = 0 give s == 0, and its entry carries ce = 1, so the
+                // resident row stays bit-identical (fma(0, p, 1*q) == q) and zeros are
+                // rewritten to the all-zero p row: no flag test, no select.
+                const float sc = __builtin_fmaf(-lr, dot, r);
                 const float4 p2 = axpy_row(sc, rq, ce, cur.p);
                 rq = axpy_row(sc, cur.p, ce, rq);
-#if MFSGD_EXP == 1
-                asm volatile("" ::"v"(p2.x), "v"(p2.y), "v"(p2.z), "v"(p2.w), "v"(cur.pa));
-#else
                 lds_st(lr_, cur.pa, p2);
-#endif
             } else {
+                const float err = r - dot;
                 acc += (double)err * (double)err;  // idle: p row and r are zero, err == 0
             }
             nxt.p = pn;
@@ -279,11 +259,11 @@ struct Cell {
             const int nr = nall >> 16;    // run steps, stored after the general ones
             // entries of this wave's sub-cell; the host pads every cell with two idle
             // steps, so reading entries t+1 and t+2 past the end stays inside the image
-            const uint2* ebase = lent + (size_t)__builtin_amdgcn_readfirstlane((int)sd.x) * G + g;
+            const uint4* ebase = lent + (size_t)__builtin_amdgcn_readfirstlane((int)sd.x) * G + g;
             unsigned long long tm0 = 0, tm1 = 0, tm2 = 0;
             if constexpr (TIMED) tm0 = __builtin_amdgcn_s_memtime();
             if (n > 0) {
-                const uint2* eptr = ebase;
+                const uint4* eptr = ebase;
                 StepRegs A, B;
                 A.en = eptr[0];
                 B.en = eptr[G];
@@ -299,7 +279,7 @@ struct Cell {
             }
             if constexpr (TIMED) tm1 = __builtin_amdgcn_s_memtime();
             if (nr > 0) {
-                const uint2* eptr = ebase + (size_t)n * G;
+                const uint4* eptr = ebase + (size_t)n * G;
                 StepRegs A, B;
                 A.en = eptr[0];
                 B.en = eptr[G];

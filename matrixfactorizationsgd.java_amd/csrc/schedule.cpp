@@ -26,7 +26,7 @@ Geometry geometry_for_k(int k) {
 
 // LDS image of a cell: rows | 2G all-zero rows | step entries | sub-cell table | row ids
 int64_t lds_bytes_for(const Geometry& geo, int W, int nrows, int64_t n_steps) {
-    int64_t b = 16 /* control block */ + (int64_t)(nrows + 2 * geo.G) * geo.rowbytes + n_steps * geo.G * 8 +
+    int64_t b = 16 /* control block */ + (int64_t)(nrows + 2 * geo.G) * geo.rowbytes + n_steps * geo.G * 16 +
                 (int64_t)W * W * 8 + (int64_t)nrows * 4;
     return (b + 15) & ~(int64_t)15;
 }
@@ -94,7 +94,20 @@ inline uint32_t encode_slots(int pslot, int qslot, bool fwd_q, int Lg) {
     return (uint32_t)(pslot * Lg) | ((uint32_t)(qslot * Lg) << 16) | (fwd_q ? 0x80000000u : 0u);
 }
 
-void pack_subcell(const Rat* rs, int n, int G, int Lg, int nrows, Scratch& sc, int32_t& tstamp,
+struct Hyper {
+    float lr, c;
+};
+
+inline Entry make_entry(uint32_t slots, float r, float ce, const Hyper& hy) {
+    Entry e;
+    e.slots = slots;
+    e.r = r;
+    e.lrr = hy.lr * r;
+    e.ce = ce;
+    return e;
+}
+
+void pack_subcell(const Rat* rs, int n, int G, int Lg, int nrows, const Hyper& hy, Scratch& sc, int32_t& tstamp,
                   std::vector<Entry>& entries, std::vector<int64_t>& order, uint32_t& n_steps) {
     n_steps = 0;
     if (n == 0) return;
@@ -171,20 +184,14 @@ void pack_subcell(const Rat* rs, int n, int G, int Lg, int nrows, Scratch& sc, i
         const size_t base = entries.size();
         entries.resize(base + (size_t)G);
         for (int g = 0; g < G; ++g) {
-            Entry e;
-            e.slots = encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, Lg);
-            e.r = 0.0f;
-            entries[base + (size_t)g] = e;
+            entries[base + (size_t)g] = make_entry(encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, Lg), 0.0f, hy.c, hy);
         }
         int64_t ord_tmp[64];
         for (int g = 0; g < G; ++g) ord_tmp[g] = -1;
         for (int j = 0; j < ntake; ++j) {
             const Rat& x = rs[sc.cand[(size_t)taken[j]]];
             const int g = slot_of[j];
-            Entry e;
-            e.slots = encode_slots(x.p, x.q, sc.prevstep[x.q] == t - 1, Lg);
-            e.r = x.r;
-            entries[base + (size_t)g] = e;
+            entries[base + (size_t)g] = make_entry(encode_slots(x.p, x.q, sc.prevstep[x.q] == t - 1, Lg), x.r, hy.c, hy);
             ord_tmp[g] = x.idx;
             sc.remdeg[x.p]--;
             sc.remdeg[x.q]--;
@@ -217,7 +224,7 @@ void pack_subcell(const Rat* rs, int n, int G, int Lg, int nrows, Scratch& sc, i
 // most one rating per slot; users are distinct inside a step and never repeat in
 // consecutive steps (their rows are prefetched one step ahead).  Idle slots carry the
 // idle flag (bit 31) and the slot's item address, so the kernel can skip them.
-void pack_run(const Rat* rs, int n, const uint16_t* run_q, int nrun, int G, int Lg, int nrows,
+void pack_run(const Rat* rs, int n, const uint16_t* run_q, int nrun, int G, int Lg, int nrows, const Hyper& hy,
               Scratch& sc, int32_t& tstamp, std::vector<Entry>& entries,
               std::vector<int64_t>& order, uint32_t& n_steps) {
     n_steps = 0;
@@ -243,11 +250,9 @@ void pack_run(const Rat* rs, int n, const uint16_t* run_q, int nrun, int G, int 
         const size_t base = entries.size();
         entries.resize(base + (size_t)G);
         for (int g = 0; g < G; ++g) {
-            Entry e;
             const int qslot = g < nrun ? (int)run_q[g] : nrows + 2 * g + 1;
-            e.slots = encode_slots(nrows + 2 * g, qslot, true, Lg);  // bit 31 = idle in a run step
-            e.r = 0.0f;
-            entries[base + (size_t)g] = e;
+            // idle run slot: zero p row, r = 0 (so s == 0) and ce = 1: the resident row is untouched
+            entries[base + (size_t)g] = make_entry(encode_slots(nrows + 2 * g, qslot, true, Lg), 0.0f, 1.0f, hy);
         }
         int64_t ord_tmp[64];
         for (int g = 0; g < G; ++g) ord_tmp[g] = -1;
@@ -260,10 +265,7 @@ void pack_run(const Rat* rs, int n, const uint16_t* run_q, int nrun, int G, int 
                 const Rat& r = rs[j];
                 if (sc.laststep[r.p] == t || sc.prevstep[r.p] == t - 1) continue;
                 sc.laststep[r.p] = t;
-                Entry e;
-                e.slots = encode_slots(r.p, r.q, false, Lg);
-                e.r = r.r;
-                entries[base + (size_t)g] = e;
+                entries[base + (size_t)g] = make_entry(encode_slots(r.p, r.q, false, Lg), r.r, hy.c, hy);
                 ord_tmp[g] = r.idx;
                 qpos[g][x] = -1;
                 --remaining;
@@ -349,6 +351,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     std::atomic<int> failed{0};
     std::string fail_msg;
     const int WW = W * W;
+    const Hyper hy{prm.lr, 1.0f - prm.lr * prm.lambda};
     auto worker = [&]() {
         Scratch sc;
         for (;;) {
@@ -436,10 +439,10 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                         ngen = (int)(std::stable_partition(sub, sub + nsub, [&](const Rat& x) { return !is_run(x); }) - sub);
                     }
                     ++tstamp;  // break stickiness across sub-cells
-                    pack_subcell(sub, ngen, G, geo.L, nrows, sc, tstamp, o.entries, o.order, ns);
+                    pack_subcell(sub, ngen, G, geo.L, nrows, hy, sc, tstamp, o.entries, o.order, ns);
                     if (nrun > 0) {
                         ++tstamp;  // the run starts with fresh loads: no hazard against the last general step
-                        pack_run(sub + ngen, nsub - ngen, run_q, nrun, G, geo.L, nrows, sc, tstamp, o.entries,
+                        pack_run(sub + ngen, nsub - ngen, run_q, nrun, G, geo.L, nrows, hy, sc, tstamp, o.entries,
                                  o.order, nr);
                     }
                     if (ns > 0xFFFF || nr > 0xFFFF) {
@@ -454,12 +457,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             }
             // two trailing idle steps: the kernel reads entries t+1 and t+2 ahead
             for (int pad = 0; pad < 2; ++pad)
-                for (int g = 0; g < G; ++g) {
-                    Entry e;
-                    e.slots = encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, geo.L);
-                    e.r = 0.0f;
-                    o.entries.push_back(e);
-                }
+                for (int g = 0; g < G; ++g)
+                    o.entries.push_back(make_entry(encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, geo.L), 0.0f, hy.c, hy));
             o.n_steps = stepcur + 2;
             o.crit = crit;
         }

@@ -56,12 +56,16 @@ struct Entry {
     // units.  General step: flag = forward, this slot's q row is the one it updated in the
     // previous step (take it from registers, not from LDS).  Run step: flag = idle slot.
     uint32_t slots;
-    float r;
+    float r;    // the rating (RMSE pass)
+    float lrr;  // lr * r, rounded once on the host (training: s = fma(-lr, dot, lrr))
+    float ce;   // decay factor of this slot's rows: c = 1 - lr*lambda, or 1 for an idle run slot
 };
+static_assert(sizeof(Entry) == 16, "Entry layout");
 
 struct SchedParams {
     int32_t U = 0, I = 0;   // row counts of P and of this partition's Q block
     int k = 0;
+    float lr = 0.f, lambda = 0.f;  // baked into the step entries (lr*r, 1 - lr*lambda)
     int B = 0;              // 0 = auto
     int W = 0;              // 0 = auto
     int lds_budget = 160 * 1024 - 512;

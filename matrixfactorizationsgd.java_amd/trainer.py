@@ -177,7 +177,7 @@ class MatrixFactorizationSGD:
         cells = np.zeros((n[0].value, 4), np.uint32)
         rows = np.zeros(n[1].value, np.uint32)
         subs = np.zeros((n[2].value, 2), np.uint32)
-        entries = np.zeros((n[3].value, 2), np.uint32)
+        entries = np.zeros((n[3].value, 4), np.uint32)
         self._check(self._lib.mfsgd_debug_get_schedule(self._handle(), int(part), _p(cells, C.c_uint32),
                                                        _p(rows, C.c_uint32), _p(subs, C.c_uint32),
                                                        _p(entries, C.c_uint32)))

@@ -119,8 +119,11 @@ float mfo_dot(const float* p, const float* q, int32_t k) { return dot_impl(p, q,
 /* dot, error, L2-regularised rank-1 update. */
 static inline __attribute__((always_inline)) float update_impl(float* p, float* q, int32_t k,
                                                                float r, float lr, float lambda) {
-    const float e = r - dot_impl(p, q, k);
-    const float s = lr * e;
+    const float dot = dot_impl(p, q, k);
+    const float e = r - dot;
+    /* s = lr*(r - dot) evaluated as one fused operation on the rounded product lr*r:
+     * a single dependent operation between the dot product and the new rows */
+    const float s = fmaf(-lr, dot, lr * r);
     const float c = 1.0f - lr * lambda;
     for (int f = 0; f < k; ++f) {
         const float pf = p[f], qf = q[f];

@@ -48,7 +48,7 @@ void mfo_init_factors(float* P, float* Q, int32_t U, int32_t I, int32_t k, int64
 float mfo_dot(const float* p, const float* q, int32_t k);
 
 /* ---- a1+a2+a3: one rating update in place ---------------------------------
- *   e = r - dot(p,q);  s = lr*e;  c = 1 - lr*lambda  (all fp32)
+ *   e = r - dot(p,q);  s = fma(-lr, dot, lr*r);  c = 1 - lr*lambda  (all fp32)
  *   p'[f] = fma(s, q[f], c*p[f]);  q'[f] = fma(s, p[f], c*q[f])   (old p,q)
  * Returns e (the error before the update).                                  */
 float mfo_sgd_update(float* p, float* q, int32_t k, float r, float lr, float lambda);

@@ -85,9 +85,14 @@ def replay_epoch(oracle, P, Q, k, lr, lam, sched, B, W, G, L):
                                 pa, qa, idle = _decode(ent(base + t, g)[0], L)
                                 assert pa == curp[g][0]
                                 if idle:
+                                    # the kernel does not test the flag: it relies on r = 0, ce = 1
+                                    assert ent(base + t, g)[1] == 0 and ent(base + t, g)[2] == 0
+                                    assert ent(base + t, g)[3:4].view(np.float32)[0] == 1.0
                                     continue
                                 assert qa == rqa[g], "run entry changes the resident item"
                                 r = float(ent(base + t, g)[1:2].view(np.float32)[0])
+                                assert ent(base + t, g)[2:3].view(np.float32)[0] == np.float32(lr) * np.float32(r)
+                                assert ent(base + t, g)[3:4].view(np.float32)[0] == np.float32(1.0) - np.float32(lr) * np.float32(lam)
                                 p2 = curp[g][1].copy()
                                 oracle.sgd_update(p2, rq[g], r, lr, lam)
                                 lds[pa] = p2

@@ -61,7 +61,8 @@ def test_update_formula_op_by_op(oracle):
         t1 = f(np.float64(p[3]) * np.float64(q[3]) + np.float64(t1))
         dot = f(t0 + t1)
         assert oracle.dot(p, q) == dot
-        e = f(r - dot); s = f(lr * e); c = f(f(1.0) - f(lr * lam))
+        e = f(r - dot); c = f(f(1.0) - f(lr * lam))
+        s = f(-np.float64(lr) * np.float64(dot) + np.float64(f(lr * r)))  # fma(-lr, dot, lr*r)
         pe = np.array([f(np.float64(s) * np.float64(q[j]) + np.float64(f(c * p[j]))) for j in range(4)], f)
         qe = np.array([f(np.float64(s) * np.float64(p[j]) + np.float64(f(c * q[j]))) for j in range(4)], f)
         p2, q2 = p.copy(), q.copy()
