@@ -102,12 +102,16 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo "
                     "(rehearsal: several ranks on one GPU, ring staged through host memory)")
+    ap.add_argument("--parts-per-rank", type=int, default=0, help="DSGD: item partitions a rank trains concurrently (0 = auto)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="debugging: run ONE rank of an N-GPU DSGD job on one "
+                    "GPU without communication (per-rank compute time of that job)")
     ap.add_argument("--round-launch", action="store_true", help="one kernel per round instead of the persistent epoch kernel")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    emu = args.emulate_world if args.emulate_world > 1 and world == 1 else 0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
@@ -138,18 +142,22 @@ def main():
     # weak scaling: every rank brings its own 138,493 users and 20 M ratings, and the item
     # catalogue grows with the rank count (N x 26,744 items), so that the longest per-row
     # dependency chain a rank has to serialise stays what it is at N = 1
-    w = synth.workload(args.workload, args.scale, seed_offset=1000 * rank, item_mult=world)
+    vworld = emu if emu else world  # ranks the problem is sized for
+    w = synth.workload(args.workload, args.scale, seed_offset=1000 * rank, item_mult=vworld)
     if rank == 0:
         log(f"generated {w['nnz']} ratings ({w['U']} x {w['I']}, {w['dist']}) in {time.time() - t0:.1f} s")
     k, nnz = w["k"], w["nnz"]
     flags = (_lib.FLAG_NO_GRAPH if args.no_graph else 0) | (_lib.FLAG_ROUND_LAUNCH if args.round_launch else 0)
 
+    # a DSGD partition of one rank is small: train several at once
+    ppr = args.parts_per_rank if args.parts_per_rank > 0 else (1 if vworld == 1 else 2)
+    n_parts = vworld * ppr if vworld > 1 else 0
     m = mfsgd_amd.MatrixFactorizationSGD(w["U"], w["I"], k, LR, LAM, SEED, device=local_rank, blocks=args.blocks,
-                                         waves=args.waves, n_parts=world if world > 1 else 0,
+                                         waves=args.waves, n_parts=n_parts,
                                          host_threads=host_threads(), flags=flags)
     t0 = time.time()
     m.set_ratings(w["u"], w["i"], w["r"])
-    infos = [m.schedule_info(p) for p in range(world)]
+    infos = [m.schedule_info(p) for p in range(max(1, n_parts))]
     if rank == 0:
         i0 = infos[0]
         log(f"schedule built in {time.time() - t0:.1f} s: B={i0['blocks']} W={i0['waves']} G={i0['slots']} "
@@ -157,7 +165,7 @@ def main():
 
     launches_per_epoch = sum((i["rounds"] if args.round_launch else 1) for i in infos if i["nnz"] > 0)
 
-    if world == 1:
+    if vworld == 1:
         m.init_factors(SEED)
         rmse0 = m.rmse()  # also moves everything to the device
         for _ in range(args.warmup):
@@ -173,22 +181,28 @@ def main():
     else:
         from mfsgd_amd.dsgd import DSGD, HipBackend, TorchDistRing
 
-        u_total = w["U"] * world
+        u_total = w["U"] * vworld
         m.init_p_offset(SEED, rank * w["U"])
         ring = TorchDistRing(dist, rank, world)
-        d = DSGD(HipBackend(m, dev), ring, rank, world, w["I"], m.kp, SEED, u_total, nnz)
+        if emu:
+            # one rank of an `emu`-rank job: the ring shift is a local copy, every group is visited
+            class _Loop(TorchDistRing):
+                def shift(self, a, b):
+                    b.copy_(a)
+            ring = _Loop(None, 0, 1)
+        d = DSGD(HipBackend(m, dev), ring, rank, vworld, w["I"], m.kp, SEED, u_total, nnz, parts_per_rank=ppr)
         sse0, n0 = ring.sum_f64([d.sse(), float(nnz)], torch, dev)
         rmse0 = (sse0 / n0) ** 0.5
         for _ in range(args.warmup):
             d.epoch()
         torch.cuda.synchronize()
-        dist.barrier()
+        ring.barrier()
         torch.cuda.synchronize()
         t_wall0 = time.perf_counter()
         for _ in range(args.steps):
             d.epoch()
         torch.cuda.synchronize()
-        dist.barrier()
+        ring.barrier()
         torch.cuda.synchronize()
         wall_s = time.perf_counter() - t_wall0
         elapsed_s = ring.max_f64(wall_s, torch, dev)
@@ -207,9 +221,9 @@ def main():
     # ---- roofline of the dominant kernel (sgd cell kernel, one launch per round) --
     # algorithmic bytes per update: 12 (COO triple) + 4 rows x 4k bytes, no reuse credited
     bytes_per_update = 16 * k + 12
-    avg_launch_s = (dev_ms / 1e3) / max(1, launches)
+    avg_launch_s = (dev_ms / 1e3) / max(1, launches)  # N > 1: partitions of a group run concurrently
     units_per_launch = nnz * args.steps / max(1, launches)  # per rank
-    achieved_gbs = units_per_launch * bytes_per_update / avg_launch_s / 1e9
+    achieved_gbs = units_per_launch * bytes_per_update / avg_launch_s / 1e9  # per GPU
     roofline = {
         "bound": "hbm",
         "kernel": ("mfsgd::cell_kernel<L,W,train> (one launch per round)" if args.round_launch
@@ -242,6 +256,7 @@ def main():
             "users_per_gpu": w["U"], "items": w["I"], "nnz_per_gpu": nnz, "k": k,
             "lr": LR, "lambda": LAM, "scale": args.scale,
             "blocks": infos[0]["blocks"], "waves": infos[0]["waves"],
+            "parts_per_rank": ppr, "emulated_world": emu,
             "parallelism": "single" if world == 1 else f"dsgd{world}" + ("-gloo-rehearsal" if args.backend == "gloo" else ""),
         },
         "rmse_before": rmse0,

@@ -49,6 +49,23 @@ class HipBackend:
     def part_train(self, part, block):
         self.t.part_train(part, block.data_ptr(), self._stream())
 
+    def part_train_many(self, parts, blocks):
+        """Trains several partitions at once: one persistent kernel each, on streams of
+        their own, so that small partitions share the GPU instead of queueing."""
+        torch = self.torch
+        if len(parts) == 1:
+            return self.part_train(parts[0], blocks[0])
+        if not hasattr(self, "_side"):
+            self._side = []
+        while len(self._side) < len(parts):
+            self._side.append(torch.cuda.Stream(device=self.device))
+        main = torch.cuda.current_stream(self.device)
+        for part, block, st in zip(parts, blocks, self._side):
+            st.wait_stream(main)
+            self.t.part_train(part, block.data_ptr(), st.cuda_stream)
+        for st in self._side[: len(parts)]:
+            main.wait_stream(st)
+
     def part_sse(self, part, block):
         return self.t.part_sse(part, block.data_ptr(), self._stream())
 
@@ -105,41 +122,70 @@ class TorchDistRing:
 
 
 class DSGD:
-    """The rotation schedule.  `backend` computes, `ring` moves blocks."""
+    """The rotation schedule.  `backend` computes, `ring` moves blocks.
 
-    def __init__(self, backend, ring, rank, world, n_items, kp, seed, u_total, nnz_local):
+    Items are cut into world * m partitions; a rank holds m of them at a time (its
+    "group": partitions group*m .. group*m + m - 1), trains them concurrently, and passes
+    the whole group along the ring.  m > 1 matters when a partition is too small to fill
+    a GPU on its own."""
+
+    def __init__(self, backend, ring, rank, world, n_items, kp, seed, u_total, nnz_local, parts_per_rank=1):
         self.b, self.ring, self.rank, self.world = backend, ring, rank, world
         self.seed, self.u_total, self.nnz_local = seed, u_total, nnz_local
-        self.max_rows = (n_items + world - 1) // world
+        self.m = int(parts_per_rank)
+        self.n_parts = world * self.m
+        self.max_rows = (n_items + self.n_parts - 1) // self.n_parts
         self.kp = kp
-        # two buffers: the block being trained and the landing zone of the next one
-        self.cur = backend.new_block(self.max_rows, kp)
-        self.nxt = backend.new_block(self.max_rows, kp)
-        self.part = rank  # partition currently held
-        backend.load_block(self.cur, backend.part_init_q(self.part, seed, u_total))
+        # two buffers of m blocks each: the group being trained and the landing zone of the next
+        self.cur = backend.new_block(self.m * self.max_rows, kp)
+        self.nxt = backend.new_block(self.m * self.max_rows, kp)
+        self.group = rank  # group currently held
+        for j, part in enumerate(self.parts()):
+            backend.load_block(self.block(j), backend.part_init_q(part, seed, u_total))
+
+    def parts(self):
+        return [self.group * self.m + j for j in range(self.m)]
+
+    def block(self, j, buf=None):
+        buf = self.cur if buf is None else buf
+        return buf[j * self.max_rows:(j + 1) * self.max_rows]
 
     def _rotate(self):
         self.ring.shift(self.cur, self.nxt)
         self.cur, self.nxt = self.nxt, self.cur
-        self.part = (self.part + 1) % self.world
+        self.group = (self.group + 1) % self.world
 
     def epoch(self):
         for _ in range(self.world):
-            self.b.part_train(self.part, self.cur)
+            parts = self.parts()
+            blocks = [self.block(j) for j in range(self.m)]
+            if self.m > 1 and hasattr(self.b, "part_train_many"):
+                self.b.part_train_many(parts, blocks)
+            else:
+                for part, blk in zip(parts, blocks):
+                    self.b.part_train(part, blk)
             self._rotate()
 
     def sse(self):
         """Sum of squared errors of this rank's ratings (one read-only rotation)."""
         total = 0.0
         for _ in range(self.world):
-            total += self.b.part_sse(self.part, self.cur)
+            for j, part in enumerate(self.parts()):
+                total += self.b.part_sse(part, self.block(j))
             self._rotate()
         return total
 
+    def home_blocks(self):
+        """{partition: host copy of its Q block} -- valid between epochs."""
+        out = {}
+        for j, part in enumerate(self.parts()):
+            rows = self.b.part_rows(part)
+            out[part] = self.b.block_to_host(self.block(j))[:rows]
+        return out
+
     def home_block(self):
-        """(partition, host copy of its Q block) -- valid between epochs."""
-        rows = self.b.part_rows(self.part)
-        return self.part, self.b.block_to_host(self.cur)[:rows]
+        part = self.parts()[0]
+        return part, self.home_blocks()[part]
 
 
 def assemble_q(blocks, n_items, k, world):

@@ -15,18 +15,21 @@ def rank_workload(rank, U_local, I, nnz, seed=100):
     return u, i, r
 
 
-def sequential_dsgd(oracle, trainers, data, U_local, I, k, G, epochs):
-    """One process, no communication: sub-epoch s, rank g trains partition (g+s)%G.
-    Within a sub-epoch the G (rank, partition) pairs are disjoint, so any order works."""
+def sequential_dsgd(oracle, trainers, data, U_local, I, k, G, epochs, parts_per_rank=1):
+    """One process, no communication: sub-epoch s, rank g trains the partitions of group
+    (g+s)%G (partitions group*m .. group*m+m-1).  Within a sub-epoch the (rank, partition)
+    pairs are disjoint, so any order works."""
+    m = parts_per_rank
     P, Q = oracle.init_factors(U_local * G, I, k, SEED)
     sse = []
     for _ in range(epochs):
         for s in range(G):
             for g in range(G):
-                part = (g + s) % G
-                u, i, r = data[g]
-                order, _ = trainers[g].order(part)
-                oracle.sgd_pass_ordered(P, Q, u + g * U_local, i, r, order, LR, LAM)
+                for j in range(m):
+                    part = ((g + s) % G) * m + j
+                    u, i, r = data[g]
+                    order, _ = trainers[g].order(part)
+                    oracle.sgd_pass_ordered(P, Q, u + g * U_local, i, r, order, LR, LAM)
         tot = 0.0
         for g in range(G):
             u, i, r = data[g]

@@ -22,35 +22,40 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     U_local, I, k, nnz, epochs = 40, 37, 8, 500, 2
+    m = int(os.environ.get("MFSGD_TEST_PARTS_PER_RANK", "1"))
+    n_parts = world * m
     orc = Oracle()
     u, i, r = rank_workload(rank, U_local, I, nnz)
-    t = mf.MatrixFactorizationSGD(U_local, I, k, LR, LAM, SEED, n_parts=world)
+    t = mf.MatrixFactorizationSGD(U_local, I, k, LR, LAM, SEED, n_parts=n_parts)
     t.set_ratings(u, i, r)
     t.init_p_offset(SEED, rank * U_local)
-    backend = OracleBackend(torch, orc, t, u, i, r, k, world)
+    backend = OracleBackend(torch, orc, t, u, i, r, k, n_parts)
     ring = TorchDistRing(dist, rank, world)
-    d = DSGD(backend, ring, rank, world, I, t.kp, SEED, U_local * world, nnz)
+    d = DSGD(backend, ring, rank, world, I, t.kp, SEED, U_local * world, nnz, parts_per_rank=m)
     sse = []
     for _ in range(epochs):
         d.epoch()
-        assert d.part == rank, "blocks are not home after an epoch"
+        assert d.group == rank, "blocks are not home after an epoch"
         tot, cnt = ring.sum_f64([d.sse(), float(nnz)], torch, torch.device("cpu"))
         assert cnt == nnz * world
         sse.append(tot)
-    part, blk = d.home_block()
     gathered = [None] * world
-    dist.all_gather_object(gathered, (rank, backend.P, part, blk))
+    dist.all_gather_object(gathered, (rank, backend.P, d.home_blocks()))
     if rank == 0:
         P = np.concatenate([g[1] for g in sorted(gathered, key=lambda x: x[0])])
-        Q = assemble_q({g[2]: g[3] for g in gathered}, I, k, world)
+        blocks = {}
+        for g in gathered:
+            blocks.update(g[2])
+        assert sorted(blocks) == list(range(n_parts))
+        Q = assemble_q(blocks, I, k, n_parts)
         trainers, data = [], []
         for g in range(world):
             ug, ig, rg = rank_workload(g, U_local, I, nnz)
-            tg = mf.MatrixFactorizationSGD(U_local, I, k, LR, LAM, SEED, n_parts=world)
+            tg = mf.MatrixFactorizationSGD(U_local, I, k, LR, LAM, SEED, n_parts=n_parts)
             tg.set_ratings(ug, ig, rg)
             trainers.append(tg)
             data.append((ug, ig, rg))
-        Ps, Qs, sse_s = sequential_dsgd(orc, trainers, data, U_local, I, k, world, epochs)
+        Ps, Qs, sse_s = sequential_dsgd(orc, trainers, data, U_local, I, k, world, epochs, parts_per_rank=m)
         assert np.array_equal(P, Ps), "P differs from the sequential DSGD definition"
         assert np.array_equal(Q, Qs), "Q differs from the sequential DSGD definition"
         assert np.allclose(sse, sse_s, rtol=1e-12), (sse, sse_s)

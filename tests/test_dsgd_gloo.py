@@ -18,9 +18,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_dsgd_ring_over_gloo(mf, world):
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+@pytest.mark.parametrize("world,m", [(2, 1), (3, 1), (2, 3)])
+def test_dsgd_ring_over_gloo(mf, world, m):
+    env = dict(os.environ, OMP_NUM_THREADS="1", MFSGD_TEST_PARTS_PER_RANK=str(m))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "dsgd_gloo_worker.py")]
