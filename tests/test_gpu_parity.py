@@ -95,6 +95,27 @@ def test_blocks_and_waves(mf, oracle, B, W):
     assert info["blocks"] == B and info["waves"] == W
 
 
+def test_more_blocks_than_resident_workgroups(mf, oracle):
+    """B = 300 > 256 CUs: the persistent kernel's workgroups each own several user blocks."""
+    rng = np.random.default_rng(300)
+    U, I, n = 2400, 1800, 60000
+    key = rng.choice(U * I, n, replace=False)
+    _, info = _run(mf, oracle, U, I, 64, key // I, key % I, rng.random(n) * 4 + 1, epochs=2, blocks=300, waves=2)
+    assert info["blocks"] == 300
+
+
+def test_round_launch_path_equals_persistent(mf, oracle):
+    from mfsgd_amd import _lib
+
+    w = mf.synth.workload("cfg2_ml20m", scale=0.03)
+    outs = []
+    for flags in (0, _lib.FLAG_ROUND_LAUNCH):
+        with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 5, flags=flags) as m:
+            m.train(w["u"], w["i"], w["r"], 3)
+            outs.append(m.get_factors())
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_eager_launch_equals_graph(mf, oracle):
     from mfsgd_amd import _lib
 
