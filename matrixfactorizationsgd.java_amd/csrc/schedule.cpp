@@ -283,6 +283,15 @@ void pack_run(const Rat* rs, int n, const uint16_t* run_q, int nrun, int G, int 
         }
         ++n_steps;
     }
+    // the kernel's run loop is unrolled by two: pad to an even number of steps with an
+    // all-idle step (p = zero row, r = 0, ce = 1 leaves the resident rows untouched)
+    if (n_steps & 1) {
+        for (int g = 0; g < G; ++g) {
+            const int qslot = g < nrun ? (int)run_q[g] : nrows + 2 * g + 1;
+            entries.push_back(make_entry(encode_slots(nrows + 2 * g, qslot, true, Lg), 0.0f, 1.0f, hy));
+        }
+        ++n_steps;
+    }
 }
 
 }  // namespace
