@@ -524,15 +524,29 @@ epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __res
     const int NP = (int)gridDim.x;
     if (cx.tid == 0) ctl[0] = 0;
     __syncthreads();
+    // the descriptor of the next (round, block) this workgroup will run is fetched one
+    // iteration ahead, so its latency never sits in front of the schedule staging
+    auto cell_of = [&](int R, int b) { return b * B + (b + R % B) % B; };
+    CellDesc cd_next = cells[cell_of(0, (int)blockIdx.x)];
     for (int R = 0; R < n_rounds; ++R) {
-        const int rd = R % B;
         for (int b = (int)blockIdx.x; b < B; b += NP) {
-            const int cell = b * B + (b + rd) % B;
-            const CellDesc cd = cells[cell];
+            const int cell = cell_of(R, b);
+            const CellDesc cd = cd_next;
+            {
+                int nb = b + NP, nR = R;
+                if (nb >= B) {
+                    nb = (int)blockIdx.x;
+                    ++nR;
+                }
+                if (nR < n_rounds) cd_next = cells[cell_of(nR, nb)];
+            }
             cx.bind(cd, smem);
             const bool work = cx.nrows != 0;  // uniform over the workgroup
             if (work) {
                 cx.stage_schedule(cd, cell, rows, subs, entries);
+                // the P rows stored at the end of the previous iteration may be gathered again
+                // now: their stores had the schedule staging above to drain behind
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 cx.gather(P, Q, 0, cx.nu);  // own rows: no dependency on other workgroups
             }
@@ -573,9 +587,9 @@ epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __res
                 __hip_atomic_store((gu32*)(done + (size_t)b * kFlagStride), (unsigned)(R + 1), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             if (work) cx.template scatter<false>(P, Q, 0, cx.nu);
-            // this workgroup re-reads these P rows in a later round: drain the stores and
-            // finish the LDS reads before the image is overwritten
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the LDS image is overwritten by the next iteration's staging: its reads (the
+            // scatter above) are complete once every wave has passed this barrier; the global
+            // stores themselves drain behind that staging (see the wait above)
             __syncthreads();
         }
     }
