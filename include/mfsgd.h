@@ -134,6 +134,29 @@ int mfsgd_predict(mfsgd_handle* h, const int32_t* u, const int32_t* i, float* ou
  * the number of sgd-round kernel launches inside it.  No RMSE pass.          */
 int mfsgd_train_timed(mfsgd_handle* h, int32_t epochs, double* elapsed_ms, int64_t* launches);
 
+/* ---- data formats either side of the path (host; csrc/io.cpp) ----------------
+ * Rating files of the datasets the configs are shaped after.  Ids in the file are
+ * arbitrary: they are compacted to dense indices (rank among the distinct ids,
+ * ascending); the original ids are returned as tables.  Errors of these functions
+ * are reported by mfsgd_io_last_error() (they have no handle).                   */
+#define MFSGD_FMT_AUTO 0
+#define MFSGD_FMT_ML_TSV 1  /* MovieLens-100K u.data: user \t item \t rating \t timestamp   */
+#define MFSGD_FMT_ML_DAT 2  /* MovieLens-1M/10M ratings.dat: user::movie::rating::time   */
+#define MFSGD_FMT_ML_CSV 3  /* MovieLens-20M/25M ratings.csv: userId,movieId,rating,time */
+#define MFSGD_FMT_NETFLIX 4 /* Netflix Prize: "movieId:" then "customerId,rating,date"   */
+typedef struct mfsgd_ratings_file mfsgd_ratings_file;
+int mfsgd_ratings_file_open(const char* path, int32_t format, mfsgd_ratings_file** out);
+int mfsgd_ratings_file_info(const mfsgd_ratings_file* f, int64_t* nnz, int32_t* n_users, int32_t* n_items);
+/* Any pointer may be NULL.  u, i, r: nnz entries; user_ids / item_ids: n_users / n_items. */
+int mfsgd_ratings_file_read(const mfsgd_ratings_file* f, int32_t* u, int32_t* i, float* r,
+                            int64_t* user_ids, int64_t* item_ids);
+void mfsgd_ratings_file_close(mfsgd_ratings_file* f);
+const char* mfsgd_io_last_error(void);
+/* Factor files: "MFSGDF01", int32 U, I, k, 0, then P (U x k) and Q (I x k), fp32 little endian. */
+int mfsgd_get_dims(const mfsgd_handle* h, int32_t* n_users, int32_t* n_items, int32_t* k);
+int mfsgd_save_factors(mfsgd_handle* h, const char* path);
+int mfsgd_load_factors(mfsgd_handle* h, const char* path);
+
 /* ---- schedule introspection (host) ---------------------------------------- */
 int mfsgd_get_schedule_info(const mfsgd_handle* h, int32_t part, mfsgd_schedule_info* out);
 /* Canonical sequential order of partition `part`: order[j] is the index (into

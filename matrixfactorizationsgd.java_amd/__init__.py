@@ -9,5 +9,6 @@ raise.
 from .trainer import MatrixFactorizationSGD, MfsgdError  # noqa: F401
 from ._lib import load_library, library_path  # noqa: F401
 from . import synth  # noqa: F401
+from .datasets import load_ratings  # noqa: F401
 
-__all__ = ["MatrixFactorizationSGD", "MfsgdError", "load_library", "library_path", "synth"]
+__all__ = ["MatrixFactorizationSGD", "MfsgdError", "load_library", "library_path", "synth", "load_ratings"]

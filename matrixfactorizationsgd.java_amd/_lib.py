@@ -75,6 +75,14 @@ SIGNATURES = {
     "mfsgd_rmse": (C.c_int, [_H, _f64p]),
     "mfsgd_predict": (C.c_int, [_H, _i32p, _i32p, _f32p, C.c_int64]),
     "mfsgd_train_timed": (C.c_int, [_H, C.c_int32, _f64p, _i64p]),
+    "mfsgd_ratings_file_open": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(_H)]),
+    "mfsgd_ratings_file_info": (C.c_int, [_H, _i64p, _i32p, _i32p]),
+    "mfsgd_ratings_file_read": (C.c_int, [_H, _i32p, _i32p, _f32p, _i64p, _i64p]),
+    "mfsgd_ratings_file_close": (None, [_H]),
+    "mfsgd_io_last_error": (C.c_char_p, []),
+    "mfsgd_get_dims": (C.c_int, [_H, _i32p, _i32p, _i32p]),
+    "mfsgd_save_factors": (C.c_int, [_H, C.c_char_p]),
+    "mfsgd_load_factors": (C.c_int, [_H, C.c_char_p]),
     "mfsgd_get_schedule_info": (C.c_int, [_H, C.c_int32, C.POINTER(ScheduleInfo)]),
     "mfsgd_get_order": (C.c_int, [_H, C.c_int32, _i64p, _i64p]),
     "mfsgd_debug_schedule_sizes": (C.c_int, [_H, C.c_int32, _i64p, _i64p, _i64p, _i64p]),

@@ -655,6 +655,14 @@ int mfsgd_predict(mfsgd_handle* h, const int32_t* u, const int32_t* i, float* ou
     return MFSGD_OK;
 }
 
+int mfsgd_get_dims(const mfsgd_handle* h, int32_t* n_users, int32_t* n_items, int32_t* k) {
+    if (!h) return MFSGD_ERR_INVALID_ARG;
+    if (n_users) *n_users = h->cfg.n_users;
+    if (n_items) *n_items = h->cfg.n_items;
+    if (k) *k = h->cfg.k;
+    return MFSGD_OK;
+}
+
 int mfsgd_get_schedule_info(const mfsgd_handle* h, int32_t part, mfsgd_schedule_info* out) {
     if (!h || !out) return fail(h, MFSGD_ERR_INVALID_ARG, "get_schedule_info: null argument");
     if (!h->have_ratings) return fail(h, MFSGD_ERR_STATE, "get_schedule_info: no ratings");

@@ -5,6 +5,8 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <queue>
@@ -299,6 +301,14 @@ void pack_run(const Rat* rs, int n, const uint16_t* run_q, int nrun, int G, int 
 int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, const float* r,
                    const int64_t* orig, int64_t n, Schedule& out, std::string& err) {
     const auto t_begin = std::chrono::steady_clock::now();
+    auto t_last = t_begin;
+    const bool trace = std::getenv("MFSGD_SCHED_TRACE") != nullptr;
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[schedule] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     const Geometry geo = geometry_for_k(prm.k);
     const int B = prm.B, W = prm.W, G = geo.G;
     if (B < 1 || W < 1 || W > 8 || prm.k < 1 || geo.L > 64) {
@@ -324,9 +334,11 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         degu[(size_t)u[j]]++;
         degi[(size_t)i[j]]++;
     }
+    lap("degrees");
     std::vector<int32_t> ubin, ibin;
     lpt_assign(degu, B * W, ubin);
     lpt_assign(degi, B * W, ibin);
+    lap("LPT partition");
     // fine bin f -> block f % B, sub-group f / B
 
     // ---- counting sort by (cell, sub-round, wave) ---------------------------
@@ -352,6 +364,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     }
     bkt.clear();
     bkt.shrink_to_fit();
+    lap("bucket (counting sort)");
 
     // ---- per-cell packing (parallel over cells) ------------------------------
     const int64_t ncell = (int64_t)B * B;
@@ -483,6 +496,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         err = fail_msg;
         return -1;
     }
+    lap("per-cell packing");
 
     // ---- concatenate in cell order; canonical order is round-major ----------
     out = Schedule{};
@@ -522,6 +536,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         out.max_cell_rows = std::max<int64_t>(out.max_cell_rows, (int64_t)o.rows.size());
         out.max_cell_steps = std::max<int64_t>(out.max_cell_steps, o.crit);
     }
+    lap("  offsets");
     out.lds_bytes = (lds_need + 15) & ~15;
     out.total_rows = tot_rows;
     out.total_steps = tot_steps;
@@ -549,6 +564,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         copier();
         for (auto& t : th) t.join();
     }
+    lap("  copy rows/entries");
     out.order.resize((size_t)n);
     out.cell_ptr.assign((size_t)ncell + 1, 0);
     int64_t pos = 0;
@@ -570,6 +586,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         err = "build_schedule: internal error, packed " + std::to_string(pos) + " of " + std::to_string(n);
         return -1;
     }
+    lap("concatenate + order");
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return 0;
 }

@@ -118,6 +118,17 @@ class MatrixFactorizationSGD:
         self._check(self._lib.mfsgd_get_factors(self._handle(), _p(P, C.c_float), _p(Q, C.c_float)))
         return P, Q
 
+    def save_factors(self, path):
+        rc = self._lib.mfsgd_save_factors(self._handle(), str(path).encode())
+        if rc != 0:
+            raise MfsgdError(rc, self._lib.mfsgd_io_last_error().decode() or self._lib.mfsgd_last_error(self._h).decode())
+
+    def load_factors(self, path):
+        rc = self._lib.mfsgd_load_factors(self._handle(), str(path).encode())
+        if rc != 0:
+            raise MfsgdError(rc, self._lib.mfsgd_io_last_error().decode() or self._lib.mfsgd_last_error(self._h).decode())
+        self._initialised = True
+
     # -- the Java surface -------------------------------------------------------
     def train(self, u, i, r, epochs, *, rmse=True):
         """Runs `epochs` SGD passes over the ratings; returns the RMSE after each

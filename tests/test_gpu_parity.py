@@ -181,6 +181,20 @@ def test_predict_and_set_factors(mf, oracle):
     np.testing.assert_array_equal(Q2, Q)
 
 
+def test_train_from_a_ratings_file(mf, oracle, tmp_path):
+    rng = np.random.default_rng(12)
+    U, I, n = 400, 300, 9000
+    key = rng.choice(U * I, n, replace=False)
+    uid, iid = (key // I) * 3 + 11, (key % I) * 7 + 5  # sparse original ids
+    r = (rng.integers(1, 11, n) * 0.5).astype(np.float32)
+    f = tmp_path / "ratings.csv"
+    f.write_text("userId,movieId,rating,timestamp\n" + "".join(f"{a},{b},{c},0\n" for a, b, c in zip(uid, iid, r)))
+    d = mf.load_ratings(f)
+    np.testing.assert_array_equal(d["user_ids"][d["u"]], uid)
+    np.testing.assert_array_equal(d["item_ids"][d["i"]], iid)
+    _run(mf, oracle, d["n_users"], d["n_items"], 32, d["u"], d["i"], d["r"], epochs=2)
+
+
 def test_train_twice_and_new_ratings(mf, oracle):
     w = mf.synth.workload("cfg1_ml100k", scale=0.2)
     with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 8) as m:
