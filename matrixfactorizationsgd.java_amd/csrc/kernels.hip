@@ -43,14 +43,32 @@ __device__ __forceinline__ float dpp_move(float v) {
 // group aligned to L).  Level m adds the value of lane (l xor m); after the
 // lower levels every lane of a 2^j sub-group holds the same value, so the
 // mirror permutations used for m = 4 and m = 8 fetch exactly that value.
+// xor-16 / xor-32 butterfly levels with the gfx950 lane-swap instructions (no LDS traffic):
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows
+// of its second; with both holding v, one ends up with the even row of each row pair in
+// both rows and the other with the odd row, so their sum is (even + odd) in every lane --
+// the same bits in both partners.  v_permlane32_swap does the same for the two 32-lane halves.
+__device__ __forceinline__ float swap_add16(float v) {
+    float t;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1"
+                 : "+v"(v), "=&v"(t));
+    return v + t;
+}
+__device__ __forceinline__ float swap_add32(float v) {
+    float t;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1"
+                 : "+v"(v), "=&v"(t));
+    return v + t;
+}
+
 template <int L>
 __device__ __forceinline__ float group_allreduce(float v) {
     if constexpr (L >= 2) v = v + dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]   : xor 1
     if constexpr (L >= 4) v = v + dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]   : xor 2
     if constexpr (L >= 8) v = v + dpp_move<0x141>(v);  // row_half_mirror       : other quad
     if constexpr (L >= 16) v = v + dpp_move<0x140>(v); // row_mirror            : other half-row
-    if constexpr (L >= 32) v = v + __shfl_xor(v, 16, 64);
-    if constexpr (L >= 64) v = v + __shfl_xor(v, 32, 64);
+    if constexpr (L >= 32) v = swap_add16(v);
+    if constexpr (L >= 64) v = swap_add32(v);
     return v;
 }
 
