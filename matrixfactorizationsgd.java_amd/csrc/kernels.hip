@@ -91,6 +91,10 @@ __device__ __forceinline__ float4 axpy_row(const float s, const float4 x, const 
     return o;
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() would also
+// drain the vector-memory counter, i.e. any LDS-DMA prefetch still in flight.
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -204,9 +208,12 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
 // Everything one workgroup does with one cell, phase by phase.  Shared by the
 // per-round kernel, the SSE pass and the persistent epoch kernel.
 //
-// LDS image (after a 16-byte control block):
-//   [rows: nrows x ROWB][2G zero rows][entries: n_steps x G x 16][subs: W*W x 8][row ids: nrows x 4]
-// rows: LDS slots [0, nu) hold p-side (user) rows, [nu, nrows) q-side (item) rows.
+// LDS image of a workgroup:
+//   [control block 16 B][schedule buffer 0: sched_cap][schedule buffer 1: sched_cap][rows ...]
+//   schedule buffer: [entries: n_steps x G x 16][subs: W*W x 8][row ids: nrows x 4]
+//   rows: [nrows x ROWB][2G zero rows]; slots [0, nu) hold p-side (user) rows, [nu, nrows) q-side (item) rows.
+// Two schedule buffers: the persistent kernel fetches the next cell's schedule (LDS-DMA)
+// while the current cell is being worked on.
 template <int L, int W>
 struct Cell {
     static constexpr int G = 64 / L;
@@ -231,14 +238,44 @@ struct Cell {
         lig = lane % L;
         laneoff = (unsigned)lig * 16u;
     }
-    __device__ __forceinline__ void bind(const CellDesc& cd, unsigned char* smem) {
+    __device__ __forceinline__ void bind(const CellDesc& cd, unsigned char* smem, int buf, int sched_cap) {
         nu = cd.nu;
         nrows = (int)cd.nu + (int)cd.ni;
         n_steps = (int)cd.n_steps;
-        lrows = smem + CTL;
-        lent = reinterpret_cast<uint4*>(lrows + (size_t)(nrows + 2 * G) * ROWB);
+        lrows = smem + CTL + 2 * (size_t)sched_cap;
+        lent = reinterpret_cast<uint4*>(smem + CTL + (size_t)buf * sched_cap);
         lsub = reinterpret_cast<uint2*>(lent + (size_t)n_steps * G);
         lids = reinterpret_cast<uint32_t*>(lsub + W * W);
+    }
+
+    // Zeroes the 2G rows idle step slots point at (r = 0 keeps them zero).
+    __device__ __forceinline__ void zero_idle_rows() {
+        for (int x = tid; x < 2 * G * L; x += NT)
+            lds_st(lrows, (unsigned)(nrows * ROWB + x * 16), make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+
+    // The schedule of ANOTHER cell -> schedule buffer `buf`, by LDS-DMA (no registers held,
+    // nothing waited for here): entries, sub-cell table, row ids, each a contiguous copy of
+    // whole 16-byte units.  The caller waits (vmcnt) and barriers before binding that buffer.
+    __device__ __forceinline__ void prefetch_schedule(const CellDesc& nd, int ncell, unsigned char* smem, int buf,
+                                                      int sched_cap, const uint32_t* __restrict__ rows,
+                                                      const SubDesc* __restrict__ subs,
+                                                      const Entry* __restrict__ entries) {
+        unsigned char* const dst = smem + CTL + (size_t)buf * sched_cap;
+        const int nn = (int)nd.nu + (int)nd.ni;
+        const int ent_bytes = (int)nd.n_steps * G * 16;
+        const int sub_bytes = W * W * 8;
+        const int ids_bytes = (nn * 4 + 15) & ~15;
+        auto copy = [&](const unsigned char* src, unsigned char* d, int bytes) {
+            for (int off0 = wave * 1024; off0 < bytes; off0 += W * 1024) {
+                const int off = off0 + lane * 16;
+                if (off < bytes)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lptr_t)(d + off0), 16, 0, 0);
+            }
+        };
+        copy(reinterpret_cast<const unsigned char*>(entries + (size_t)nd.ent_off * G), dst, ent_bytes);
+        copy(reinterpret_cast<const unsigned char*>(subs + (size_t)ncell * W * W), dst + ent_bytes, sub_bytes);
+        copy(reinterpret_cast<const unsigned char*>(rows + nd.row_off), dst + ent_bytes + sub_bytes, ids_bytes);
     }
 
     // Row ids, step entries and the sub-cell table -> LDS; zeroes the idle rows.
@@ -252,9 +289,7 @@ struct Cell {
         const int ne = n_steps * G;
         for (int x = tid; x < ne; x += NT) lent[x] = gent[x];
         if (tid < W * W) lsub[tid] = reinterpret_cast<const uint2*>(subs)[(size_t)cell * W * W + tid];
-        // idle slots of a step point at these all-zero rows: r = 0 keeps them zero
-        for (int x = tid; x < 2 * G * L; x += NT)
-            lds_st(lrows, (unsigned)(nrows * ROWB + x * 16), make_float4(0.f, 0.f, 0.f, 0.f));
+        zero_idle_rows();
     }
 
     // Factor rows of LDS slots [lo, hi) -> LDS, straight from memory (LDS-DMA).  One
@@ -432,7 +467,7 @@ struct Cell {
                     o[3] = (unsigned long long)nr;
                 }
             }
-            if constexpr (TRAIN) __syncthreads();
+            if constexpr (TRAIN) wg_barrier();
         }
     }
 };
@@ -444,7 +479,7 @@ __global__ void __launch_bounds__(64 * W)
 cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __restrict__ cells,
             const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs,
             const Entry* __restrict__ entries, const int B, const int rd, const float lr,
-            const float c, double* __restrict__ sse_partial) {
+            const float c, double* __restrict__ sse_partial, const int sched_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Cell<L, W> cx;
     cx.init_thread();
@@ -455,7 +490,7 @@ cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __rest
         stamp0 = __builtin_amdgcn_s_memtime();
         real0 = __builtin_amdgcn_s_memrealtime();
     }
-    cx.bind(cd, smem);
+    cx.bind(cd, smem, 0, sched_cap);
     if (cx.nrows == 0) {  // uniform over the workgroup
         if (!TRAIN && cx.tid == 0) sse_partial[cell] = 0.0;
         return;
@@ -533,7 +568,8 @@ __global__ void __launch_bounds__(64 * W)
 epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __restrict__ cells,
              const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs,
              const Entry* __restrict__ entries, const int B, const int n_rounds, const float lr,
-             const float c, unsigned* __restrict__ done, unsigned* __restrict__ abort_word) {
+             const float c, unsigned* __restrict__ done, unsigned* __restrict__ abort_word,
+             const int sched_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using gu32 = __attribute__((address_space(1))) unsigned;
     volatile unsigned* const ctl = reinterpret_cast<volatile unsigned*>(smem);  // [0] = abort broadcast
@@ -541,75 +577,90 @@ epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __res
     cx.init_thread();
     const int NP = (int)gridDim.x;
     if (cx.tid == 0) ctl[0] = 0;
-    __syncthreads();
-    // the descriptor of the next (round, block) this workgroup will run is fetched one
-    // iteration ahead, so its latency never sits in front of the schedule staging
+
+    // This workgroup's work list: (round R, block b) for b = blockIdx.x, +NP, ... in round order.
     auto cell_of = [&](int R, int b) { return b * B + (b + R % B) % B; };
-    CellDesc cd_next = cells[cell_of(0, (int)blockIdx.x)];
-    for (int R = 0; R < n_rounds; ++R) {
-        for (int b = (int)blockIdx.x; b < B; b += NP) {
-            const int cell = cell_of(R, b);
-            const CellDesc cd = cd_next;
-            {
-                int nb = b + NP, nR = R;
-                if (nb >= B) {
-                    nb = (int)blockIdx.x;
-                    ++nR;
-                }
-                if (nR < n_rounds) cd_next = cells[cell_of(nR, nb)];
-            }
-            cx.bind(cd, smem);
-            const bool work = cx.nrows != 0;  // uniform over the workgroup
-            if (work) {
-                cx.stage_schedule(cd, cell, rows, subs, entries);
-                // the P rows stored at the end of the previous iteration may be gathered again
-                // now: their stores had the schedule staging above to drain behind
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                cx.gather(P, Q, 0, cx.nu);  // own rows: no dependency on other workgroups
-            }
-            if (R > 0) {
-                // wait until block b + 1 has finished round R - 1 (it held our tile)
-                if (cx.tid == 0) {
-                    gu32* flag = (gu32*)(done + (size_t)((b + 1) % B) * kFlagStride);
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)R) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if ((++spins & 255u) == 0u) {
-                            if (__hip_atomic_load((gu32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-                                spins > (1u << 22)) {
-                                __hip_atomic_store((gu32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                ctl[0] = 1;
-                                break;
-                            }
+    auto advance = [&](int& R, int& b) {
+        b += NP;
+        if (b >= B) {
+            b = (int)blockIdx.x;
+            ++R;
+        }
+    };
+    // Software pipeline over the list: descriptors are fetched two items ahead (registers),
+    // schedules one item ahead (LDS-DMA into the other schedule buffer).
+    int R = 0, b = (int)blockIdx.x;
+    int R1 = R, b1 = b;
+    advance(R1, b1);
+    int R2 = R1, b2 = b1;
+    advance(R2, b2);
+    CellDesc cd = cells[cell_of(R, b)];
+    CellDesc cd1 = R1 < n_rounds ? cells[cell_of(R1, b1)] : cd;
+    int buf = 0;
+    cx.bind(cd, smem, buf, sched_cap);
+    cx.stage_schedule(cd, cell_of(R, b), rows, subs, entries);  // the first one synchronously
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+
+    for (; R < n_rounds;) {
+        CellDesc cd2 = cd1;
+        if (R2 < n_rounds) cd2 = cells[cell_of(R2, b2)];  // used two iterations from now
+        cx.bind(cd, smem, buf, sched_cap);
+        const bool work = cx.nrows != 0;  // uniform over the workgroup
+        cx.zero_idle_rows();
+        // The P rows stored at the end of the previous iteration may be gathered again below.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (R1 < n_rounds) cx.prefetch_schedule(cd1, cell_of(R1, b1), smem, buf ^ 1, sched_cap, rows, subs, entries);
+        if (work) cx.gather(P, Q, 0, cx.nu);  // own rows: no dependency on other workgroups
+        if (R > 0) {
+            // wait until block b + 1 has finished round R - 1 (it held our tile)
+            if (cx.tid == 0) {
+                gu32* flag = (gu32*)(done + (size_t)((b + 1) % B) * kFlagStride);
+                unsigned spins = 0;
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)R) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((++spins & 255u) == 0u) {
+                        if (__hip_atomic_load((gu32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                            spins > (1u << 22)) {
+                            __hip_atomic_store((gu32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ctl[0] = 1;
+                            break;
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-            }
-            __syncthreads();
-            if (ctl[0] != 0) return;  // uniform: some workgroup timed out
-            if (work) {
-                cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                double acc = 0.0;
-                cx.template apply<true>(lr, c, acc);  // ends with a workgroup barrier
-                cx.template scatter<true>(P, Q, cx.nu, cx.nrows);
             }
-            // publish the tile: every storing wave drains, then one lane signals
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (cx.tid == 0)
-                __hip_atomic_store((gu32*)(done + (size_t)b * kFlagStride), (unsigned)(R + 1), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            if (work) cx.template scatter<false>(P, Q, 0, cx.nu);
-            // the LDS image is overwritten by the next iteration's staging: its reads (the
-            // scatter above) are complete once every wave has passed this barrier; the global
-            // stores themselves drain behind that staging (see the wait above)
-            __syncthreads();
         }
+        wg_barrier();
+        if (ctl[0] != 0) return;  // uniform: some workgroup timed out
+        if (work) {
+            cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows (and the prefetched schedule) have landed
+            wg_barrier();
+            double acc = 0.0;
+            cx.template apply<true>(lr, c, acc);  // ends with a workgroup barrier
+            cx.template scatter<true>(P, Q, cx.nu, cx.nrows);
+        }
+        // publish the tile: every storing wave drains, then one lane signals
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wg_barrier();
+        if (cx.tid == 0)
+            __hip_atomic_store((gu32*)(done + (size_t)b * kFlagStride), (unsigned)(R + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (work) cx.template scatter<false>(P, Q, 0, cx.nu);
+        // The rows image and this schedule buffer are reused from here on: their LDS reads (the
+        // scatter above) are complete once every wave has passed this barrier.  The next
+        // schedule has been complete since the vmcnt(0) + barrier above.
+        wg_barrier();
+        buf ^= 1;
+        cd = cd1;
+        cd1 = cd2;
+        R = R1;
+        b = b1;
+        R1 = R2;
+        b1 = b2;
+        advance(R2, b2);
     }
 }
 
@@ -665,13 +716,13 @@ hipError_t launch_cell_LW(bool train, const CellLaunch& a, hipStream_t st) {
         e = hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((cell_kernel<L, W, true, true>), grid, block, (size_t)a.lds_bytes, st, a.P, a.Q,
-                           a.cells, a.rows, a.subs, a.entries, a.B, a.rd, a.lr, a.c, a.sse_partial);
+                           a.cells, a.rows, a.subs, a.entries, a.B, a.rd, a.lr, a.c, a.sse_partial, a.sched_cap);
     } else if (train)
         hipLaunchKernelGGL((cell_kernel<L, W, true>), grid, block, (size_t)a.lds_bytes, st, a.P, a.Q,
-                           a.cells, a.rows, a.subs, a.entries, a.B, a.rd, a.lr, a.c, a.sse_partial);
+                           a.cells, a.rows, a.subs, a.entries, a.B, a.rd, a.lr, a.c, a.sse_partial, a.sched_cap);
     else
         hipLaunchKernelGGL((cell_kernel<L, W, false>), grid, block, (size_t)a.lds_bytes, st, a.P, a.Q,
-                           a.cells, a.rows, a.subs, a.entries, a.B, a.rd, a.lr, a.c, a.sse_partial);
+                           a.cells, a.rows, a.subs, a.entries, a.B, a.rd, a.lr, a.c, a.sse_partial, a.sched_cap);
     return hipGetLastError();
 }
 
@@ -685,7 +736,7 @@ hipError_t epoch_LW(int what, const CellLaunch& a, int n_rounds, unsigned* done,
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, 64 * W, (size_t)a.lds_bytes);
     }
     hipLaunchKernelGGL((epoch_kernel<L, W>), dim3((unsigned)a.grid), dim3(64 * W), (size_t)a.lds_bytes, st, a.P, a.Q,
-                       a.cells, a.rows, a.subs, a.entries, a.B, n_rounds, a.lr, a.c, done, abort_word);
+                       a.cells, a.rows, a.subs, a.entries, a.B, n_rounds, a.lr, a.c, done, abort_word, a.sched_cap);
     return hipGetLastError();
 }
 

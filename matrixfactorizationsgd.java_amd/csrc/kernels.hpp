@@ -20,6 +20,7 @@ struct CellLaunch {
     int rd;          // round (training only)
     int grid;        // workgroups: B for a training round, B*B for an SSE pass
     int lds_bytes;   // dynamic LDS per workgroup
+    int sched_cap;   // bytes of one of its two schedule buffers
     float lr;
     float c;         // 1 - lr*lambda
     double* sse_partial;

@@ -26,12 +26,12 @@ Geometry geometry_for_k(int k) {
     return g;
 }
 
-// LDS image of a cell: rows | 2G all-zero rows | step entries | sub-cell table | row ids
-int64_t lds_bytes_for(const Geometry& geo, int W, int nrows, int64_t n_steps) {
-    int64_t b = 16 /* control block */ + (int64_t)(nrows + 2 * geo.G) * geo.rowbytes + n_steps * geo.G * 16 +
-                (int64_t)W * W * 8 + (int64_t)nrows * 4;
+int64_t sched_bytes_for(const Geometry& geo, int W, int nrows, int64_t n_steps) {
+    const int64_t b = n_steps * geo.G * 16 + (int64_t)W * W * 8 + (int64_t)nrows * 4;
     return (b + 15) & ~(int64_t)15;
 }
+
+int64_t rows_bytes_for(const Geometry& geo, int nrows) { return (int64_t)(nrows + 2 * geo.G) * geo.rowbytes; }
 
 namespace {
 
@@ -507,7 +507,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     out.cells.resize((size_t)ncell);
     out.subs.resize((size_t)(ncell * WW));
     int64_t tot_rows = 0, tot_steps = 0;
-    int lds_need = 0;
+    int64_t sched_cap = 0, rows_cap = 0;
     for (int64_t c = 0; c < ncell; ++c) {
         const CellOut& o = co[(size_t)c];
         if (tot_rows > 0xFFFFFFFFll - (int64_t)o.rows.size() || tot_steps > 0xFFFFFFFFll - o.n_steps) {
@@ -525,22 +525,26 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             out.subs[(size_t)(c * WW + x)] = o.subs.empty() ? SubDesc{0, 0} : o.subs[(size_t)x];
         tot_rows += (int64_t)o.rows.size();
         tot_steps += o.n_steps;
-        const int64_t need = lds_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps);
-        if (need > prm.lds_budget) {
-            err = "lds: a cell needs " + std::to_string(need) + " bytes of LDS (budget " +
-                  std::to_string(prm.lds_budget) + "); use more blocks";
-            return -1;
-        }
-        lds_need = std::max<int>(lds_need, (int)need);
+        sched_cap = std::max(sched_cap, sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps));
+        rows_cap = std::max(rows_cap, rows_bytes_for(geo, (int)(o.nu + o.ni)));
         out.max_cell_nnz = std::max<int64_t>(out.max_cell_nnz, (int64_t)o.order.size());
         out.max_cell_rows = std::max<int64_t>(out.max_cell_rows, (int64_t)o.rows.size());
         out.max_cell_steps = std::max<int64_t>(out.max_cell_steps, o.crit);
     }
     lap("  offsets");
-    out.lds_bytes = (lds_need + 15) & ~15;
+    {
+        const int64_t need = 16 + 2 * sched_cap + rows_cap;
+        if (need > prm.lds_budget) {
+            err = "lds: the largest cell needs " + std::to_string(need) + " bytes of LDS (budget " +
+                  std::to_string(prm.lds_budget) + "); use more blocks";
+            return -1;
+        }
+        out.lds_bytes = (int)((need + 15) & ~(int64_t)15);
+        out.sched_cap = (int)sched_cap;
+    }
     out.total_rows = tot_rows;
     out.total_steps = tot_steps;
-    out.rows.resize((size_t)tot_rows);
+    out.rows.resize((size_t)tot_rows + 4, 0u);  // +16 B: the staging DMA reads whole 16-byte units
     out.entries.resize((size_t)(tot_steps * G));
     {
         std::atomic<int64_t> nc{0};

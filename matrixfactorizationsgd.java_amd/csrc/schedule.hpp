@@ -34,7 +34,11 @@ struct Geometry {
     int rowbytes;  // 16 * L
 };
 Geometry geometry_for_k(int k);
-int64_t lds_bytes_for(const Geometry& geo, int W, int nrows, int64_t n_steps);
+// LDS image of a workgroup: [control 16 B][schedule buffer 0][schedule buffer 1][rows].
+// A schedule buffer holds one cell's step entries, sub-cell table and row ids; there are
+// two so that the next cell's can be fetched while the current cell is being applied.
+int64_t sched_bytes_for(const Geometry& geo, int W, int nrows, int64_t n_steps);
+int64_t rows_bytes_for(const Geometry& geo, int nrows);
 
 // Device-facing records (layout shared with kernels.hip).
 struct CellDesc {
@@ -77,7 +81,8 @@ struct Schedule {
     Geometry geo{};
     int B = 0, W = 0;
     int64_t nnz = 0;
-    int lds_bytes = 0;
+    int lds_bytes = 0;   // 16 + 2 * sched_cap + largest rows image
+    int sched_cap = 0;   // bytes of one schedule buffer (largest cell, multiple of 16)
     std::vector<CellDesc> cells;    // B*B, index ub*B + it
     std::vector<uint32_t> rows;     // per cell: nu user rows then ni item rows
     std::vector<SubDesc> subs;      // (cell*W + s)*W + w

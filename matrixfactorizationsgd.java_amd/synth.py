@@ -31,6 +31,8 @@ WORKLOADS = {
     "cfg1_ml100k": dict(U=943, I=1682, nnz=100_000, k=32, dist="uniform", seed=2),
     "cfg2_ml20m": dict(U=138_493, I=26_744, nnz=20_000_000, k=64, dist="zm", seed=3,
                        q_user=370.0, q_item=40.0),
+    # same shape as cfg2 with uniform popularity: no long per-row chains (throughput-bound regime)
+    "cfg2_uniform": dict(U=138_493, I=26_744, nnz=20_000_000, k=64, dist="uniform", seed=13),
     "cfg3_netflix": dict(U=480_189, I=17_770, nnz=100_000_000, k=128, dist="zm", seed=4,
                          q_user=800.0, q_item=12.0),
     "cfg4_powerlaw": dict(U=10_000_000, I=1_000_000, nnz=1_000_000_000, k=256, dist="zm", seed=5,
