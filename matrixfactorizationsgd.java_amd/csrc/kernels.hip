@@ -24,10 +24,6 @@
 
 #pragma clang fp contract(off)
 
-// Timing-only ablations of the run loop (tools/exp.sh); results are wrong when != 0.
-#ifndef MFSGD_EXP
-#define MFSGD_EXP 0
-#endif
 
 namespace mfsgd {
 
