@@ -88,6 +88,8 @@ typedef struct mfsgd_schedule_info {
     int64_t max_cell_steps; /* critical path of the slowest cell (sum over sub-rounds of max wave steps) */
     int64_t sum_round_steps; /* sum over rounds of the slowest cell's critical path */
     double build_seconds;
+    int32_t swapped;      /* 1: roles exchanged (users on the kernel's forwarding side): in the   */
+    int32_t reserved0;    /*    debug schedule arrays "p-side" rows are then ITEM rows            */
 } mfsgd_schedule_info;
 
 /* ---- lifetime ------------------------------------------------------------- */

@@ -45,6 +45,8 @@ class ScheduleInfo(C.Structure):
         ("max_cell_steps", C.c_int64),
         ("sum_round_steps", C.c_int64),
         ("build_seconds", C.c_double),
+        ("swapped", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
     def as_dict(self):

@@ -41,6 +41,10 @@ struct DevBuf {
 struct Part {
     Schedule sched;
     int32_t q_rows = 0;  // rows of this partition's Q block
+    // Forwarding and register-resident runs exist on the kernel's q side only.  The update is
+    // symmetric in p and q, so when the heaviest USER outweighs the heaviest item the schedule
+    // is built with the roles exchanged and the kernels get (Q, P) instead of (P, Q).
+    bool swapped = false;
     bool on_device = false;
     DevBuf d_cells, d_rows, d_subs, d_entries, d_sse_partial, d_sse_out;
     DevBuf d_sync;        // persistent kernel: done[B] words (kDoneStride apart) + the abort word
@@ -183,8 +187,8 @@ int factors_to_device(mfsgd_handle* h) {
 
 CellLaunch make_launch(const mfsgd_handle* h, const Part& p, float* Q) {
     CellLaunch a{};
-    a.P = static_cast<float*>(h->dP.p);
-    a.Q = Q;
+    a.P = p.swapped ? Q : static_cast<float*>(h->dP.p);
+    a.Q = p.swapped ? static_cast<float*>(h->dP.p) : Q;
     a.cells = static_cast<const CellDesc*>(p.d_cells.p);
     a.rows = static_cast<const uint32_t*>(p.d_rows.p);
     a.subs = static_cast<const SubDesc*>(p.d_subs.p);
@@ -434,10 +438,27 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
         if (G == 1) {
             Part& p = h->parts[0];
             p.q_rows = h->cfg.n_items;
-            prm.I = p.q_rows;
+            // which side carries the longest chain?
+            std::vector<int32_t> du((size_t)h->cfg.n_users, 0), di((size_t)h->cfg.n_items, 0);
+            for (int64_t j = 0; j < nnz; ++j) {
+                du[(size_t)u[j]]++;
+                di[(size_t)i[j]]++;
+            }
+            const int32_t mu = du.empty() ? 0 : *std::max_element(du.begin(), du.end());
+            const int32_t mi = di.empty() ? 0 : *std::max_element(di.begin(), di.end());
+            p.swapped = mu > mi;
             std::string err;
-            if (build_schedule_auto(prm, u, i, r, nullptr, nnz, p.sched, err) != 0)
-                return fail(h, MFSGD_ERR_SCHEDULE, err);
+            int rc;
+            if (p.swapped) {
+                prm.U = h->cfg.n_items;
+                prm.I = h->cfg.n_users;
+                rc = build_schedule_auto(prm, i, u, r, nullptr, nnz, p.sched, err);
+                prm.U = h->cfg.n_users;
+            } else {
+                prm.I = p.q_rows;
+                rc = build_schedule_auto(prm, u, i, r, nullptr, nnz, p.sched, err);
+            }
+            if (rc != 0) return fail(h, MFSGD_ERR_SCHEDULE, err);
         } else {
             // item i -> partition i % G, local row i / G
             std::vector<int64_t> cnt((size_t)G, 0);
@@ -686,6 +707,7 @@ int mfsgd_get_schedule_info(const mfsgd_handle* h, int32_t part, mfsgd_schedule_
     out->max_cell_steps = s.max_cell_steps;
     out->sum_round_steps = s.sum_round_steps;
     out->build_seconds = s.build_seconds;
+    out->swapped = h->parts[(size_t)part].swapped ? 1 : 0;
     return MFSGD_OK;
 }
 

@@ -537,6 +537,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         if (need > prm.lds_budget) {
             err = "lds: the largest cell needs " + std::to_string(need) + " bytes of LDS (budget " +
                   std::to_string(prm.lds_budget) + "); use more blocks";
+            out.lds_bytes = (int)std::min<int64_t>(need, 0x7FFFFFFF);  // tells build_schedule_auto how far off it was
             return -1;
         }
         out.lds_bytes = (int)((need + 15) & ~(int64_t)15);
@@ -632,7 +633,14 @@ int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, con
         const int rc = build_schedule(prm, u, i, r, orig, n, out, err);
         if (rc == 0) return 0;
         if (!autoB || err.compare(0, 4, "lds:") != 0) return rc;
+        // the rows of the offending cell shrink roughly like 1/B: jump straight to a B that fits
         int64_t nb = B <= prm.n_cu / 2 ? (int64_t)B * 2 : ((int64_t)B / prm.n_cu + 1) * prm.n_cu;
+        if (out.lds_bytes > prm.lds_budget) {
+            const double ratio = (double)out.lds_bytes / (double)prm.lds_budget * 1.08;
+            int64_t want = (int64_t)std::ceil((double)B * ratio);
+            want = want <= prm.n_cu ? (want + 7) / 8 * 8 : (want + prm.n_cu - 1) / prm.n_cu * prm.n_cu;
+            nb = std::max(nb, want);
+        }
         const int64_t lim = std::max<int64_t>(1, minrows / W);
         if (nb > lim) {
             if (W > 1) {

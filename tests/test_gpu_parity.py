@@ -155,6 +155,16 @@ def test_hot_item_chain_run_mode(mf, oracle):
     _run(mf, oracle, U, I, 64, key // I, key % I, rng.random(key.size) * 4 + 1, epochs=2)
 
 
+def test_hot_user_chain_swapped_roles(mf, oracle):
+    rng = np.random.default_rng(19)
+    U, I = 60, 3000
+    u = [7] * I + list(rng.integers(0, U, 6000))
+    i = list(range(I)) + list(rng.integers(0, I, 6000))
+    key = np.unique(np.array(u) * I + np.array(i))
+    _, info = _run(mf, oracle, U, I, 64, key // I, key % I, rng.random(key.size) * 4 + 1, epochs=2)
+    assert info["swapped"] == 1
+
+
 def test_large_values_and_zero_lambda(mf, oracle):
     rng = np.random.default_rng(3)
     U, I, n = 200, 150, 5000

@@ -26,7 +26,10 @@ def _check(mf, oracle, U, I, k, u, i, r, replay=True, **kw):
         Pe, Qe = P.copy(), Q.copy()
         for _ in range(2):
             oracle.sgd_pass_ordered(P, Q, u, i, r, order, LR, LAM)
-            replay_epoch(oracle, Pe, Qe, k, LR, LAM, sched, info["blocks"], info["waves"], info["slots"], info["group_lanes"])
+            if info["swapped"]:  # users sit on the kernel's q side: hand the replay (Q, P)
+                replay_epoch(oracle, Qe, Pe, k, LR, LAM, sched, info["blocks"], info["waves"], info["slots"], info["group_lanes"])
+            else:
+                replay_epoch(oracle, Pe, Qe, k, LR, LAM, sched, info["blocks"], info["waves"], info["slots"], info["group_lanes"])
         np.testing.assert_array_equal(Pe, P)
         np.testing.assert_array_equal(Qe, Q)
     return info
@@ -90,6 +93,17 @@ def test_hot_item_runs(mf, oracle):
     key = np.unique(np.array(u) * I + np.array(i))
     info = _check(mf, oracle, U, I, 64, key // I, key % I, rng.random(key.size), blocks=2, waves=2)
     assert info["total_steps"] > 0
+
+
+def test_hot_user_swaps_roles(mf, oracle):
+    # one user rating 300 items: the chain is on the user side, so the roles are exchanged
+    rng = np.random.default_rng(10)
+    U, I = 50, 300
+    u = [7] * I + list(rng.integers(0, U, 600))
+    i = list(range(I)) + list(rng.integers(0, I, 600))
+    key = np.unique(np.array(u) * I + np.array(i))
+    info = _check(mf, oracle, U, I, 64, key // I, key % I, rng.random(key.size), blocks=2, waves=2)
+    assert info["swapped"] == 1
 
 
 def test_schedule_is_deterministic(mf):
