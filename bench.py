@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo "
                     "(rehearsal: several ranks on one GPU, ring staged through host memory)")
-    ap.add_argument("--parts-per-rank", type=int, default=0, help="DSGD: item partitions a rank trains concurrently (0 = auto)")
+    ap.add_argument("--parts-per-rank", type=int, default=0, help="DSGD: item partitions a rank holds at a time (0 = 1)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debugging: run ONE rank of an N-GPU DSGD job on one "
                     "GPU without communication (per-rank compute time of that job)")
     ap.add_argument("--round-launch", action="store_true", help="one kernel per round instead of the persistent epoch kernel")
@@ -149,8 +149,9 @@ def main():
     k, nnz = w["k"], w["nnz"]
     flags = (_lib.FLAG_NO_GRAPH if args.no_graph else 0) | (_lib.FLAG_ROUND_LAUNCH if args.round_launch else 0)
 
-    # a DSGD partition of one rank is small: train several at once
-    ppr = args.parts_per_rank if args.parts_per_rank > 0 else (1 if vworld == 1 else 2)
+    # partitions of one rank share its users, so they are trained one after another; more than
+    # one per rank only makes the schedules smaller
+    ppr = args.parts_per_rank if args.parts_per_rank > 0 else 1
     n_parts = vworld * ppr if vworld > 1 else 0
     m = mfsgd_amd.MatrixFactorizationSGD(w["U"], w["I"], k, LR, LAM, SEED, device=local_rank, blocks=args.blocks,
                                          waves=args.waves, n_parts=n_parts,

@@ -202,7 +202,8 @@ int mfsgd_part_rows(const mfsgd_handle* h, int32_t part, int32_t* rows);
 int mfsgd_part_init_q(const mfsgd_handle* h, int32_t part, int64_t seed, int64_t u_total,
                       float* q_block_host);
 /* One DSGD sub-epoch: every rating of this handle's users whose item is in
- * `part`, against q_block_dev.  Asynchronous on `stream`.                     */
+ * `part`, against q_block_dev.  Asynchronous on `stream`.  Calls for different
+ * partitions of ONE handle must not overlap in time: they update the same P rows. */
 int mfsgd_part_train(mfsgd_handle* h, int32_t part, float* q_block_dev, void* stream);
 /* Sum of squared errors of the same ratings (fp64), synchronous. */
 int mfsgd_part_sse(mfsgd_handle* h, int32_t part, const float* q_block_dev, void* stream,

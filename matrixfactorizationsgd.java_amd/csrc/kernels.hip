@@ -559,19 +559,18 @@ cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __rest
 // spin is bounded and raises *abort_word instead of hanging.
 constexpr int kFlagStride = 32;  // one done[] word per 128-byte line
 
+// One ring: workgroup `wg` of `NP` runs its share of the B x n_rounds cells of one schedule.
 template <int L, int W>
-__global__ void __launch_bounds__(64 * W)
-epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __restrict__ cells,
-             const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs,
-             const Entry* __restrict__ entries, const int B, const int n_rounds, const float lr,
-             const float c, unsigned* __restrict__ done, unsigned* __restrict__ abort_word,
-             const int sched_cap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict__ P, float* __restrict__ Q,
+                                         const CellDesc* __restrict__ cells, const uint32_t* __restrict__ rows,
+                                         const SubDesc* __restrict__ subs, const Entry* __restrict__ entries,
+                                         const int B, const int n_rounds, const float lr, const float c,
+                                         unsigned* __restrict__ done, unsigned* __restrict__ abort_word,
+                                         const int sched_cap, const int wg, const int NP) {
     using gu32 = __attribute__((address_space(1))) unsigned;
     volatile unsigned* const ctl = reinterpret_cast<volatile unsigned*>(smem);  // [0] = abort broadcast
     Cell<L, W> cx;
     cx.init_thread();
-    const int NP = (int)gridDim.x;
     if (cx.tid == 0) ctl[0] = 0;
 
     // This workgroup's work list: (round R, block b) for b = blockIdx.x, +NP, ... in round order.
@@ -579,13 +578,13 @@ epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __res
     auto advance = [&](int& R, int& b) {
         b += NP;
         if (b >= B) {
-            b = (int)blockIdx.x;
+            b = wg;
             ++R;
         }
     };
     // Software pipeline over the list: descriptors are fetched two items ahead (registers),
     // schedules one item ahead (LDS-DMA into the other schedule buffer).
-    int R = 0, b = (int)blockIdx.x;
+    int R = 0, b = wg;
     int R1 = R, b1 = b;
     advance(R1, b1);
     int R2 = R1, b2 = b1;
@@ -658,6 +657,18 @@ epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __res
         b1 = b2;
         advance(R2, b2);
     }
+}
+
+template <int L, int W>
+__global__ void __launch_bounds__(64 * W)
+epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __restrict__ cells,
+             const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs,
+             const Entry* __restrict__ entries, const int B, const int n_rounds, const float lr,
+             const float c, unsigned* __restrict__ done, unsigned* __restrict__ abort_word,
+             const int sched_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    run_ring<L, W>(smem, P, Q, cells, rows, subs, entries, B, n_rounds, lr, c, done, abort_word, sched_cap,
+                   (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Fixed-order reduction of the per-cell partial sums (one workgroup).

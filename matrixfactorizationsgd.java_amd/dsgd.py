@@ -49,23 +49,6 @@ class HipBackend:
     def part_train(self, part, block):
         self.t.part_train(part, block.data_ptr(), self._stream())
 
-    def part_train_many(self, parts, blocks):
-        """Trains several partitions at once: one persistent kernel each, on streams of
-        their own, so that small partitions share the GPU instead of queueing."""
-        torch = self.torch
-        if len(parts) == 1:
-            return self.part_train(parts[0], blocks[0])
-        if not hasattr(self, "_side"):
-            self._side = []
-        while len(self._side) < len(parts):
-            self._side.append(torch.cuda.Stream(device=self.device))
-        main = torch.cuda.current_stream(self.device)
-        for part, block, st in zip(parts, blocks, self._side):
-            st.wait_stream(main)
-            self.t.part_train(part, block.data_ptr(), st.cuda_stream)
-        for st in self._side[: len(parts)]:
-            main.wait_stream(st)
-
     def part_sse(self, part, block):
         return self.t.part_sse(part, block.data_ptr(), self._stream())
 
@@ -125,9 +108,9 @@ class DSGD:
     """The rotation schedule.  `backend` computes, `ring` moves blocks.
 
     Items are cut into world * m partitions; a rank holds m of them at a time (its
-    "group": partitions group*m .. group*m + m - 1), trains them concurrently, and passes
-    the whole group along the ring.  m > 1 matters when a partition is too small to fill
-    a GPU on its own."""
+    "group": partitions group*m .. group*m + m - 1), trains them ONE AFTER ANOTHER -- they
+    share the rank's users, so they cannot run concurrently -- and passes the whole group
+    along the ring.  m = 1 is the normal case; m > 1 only makes the schedules smaller."""
 
     def __init__(self, backend, ring, rank, world, n_items, kp, seed, u_total, nnz_local, parts_per_rank=1):
         self.b, self.ring, self.rank, self.world = backend, ring, rank, world
@@ -157,13 +140,8 @@ class DSGD:
 
     def epoch(self):
         for _ in range(self.world):
-            parts = self.parts()
-            blocks = [self.block(j) for j in range(self.m)]
-            if self.m > 1 and hasattr(self.b, "part_train_many"):
-                self.b.part_train_many(parts, blocks)
-            else:
-                for part, blk in zip(parts, blocks):
-                    self.b.part_train(part, blk)
+            for j, part in enumerate(self.parts()):
+                self.b.part_train(part, self.block(j))
             self._rotate()
 
     def sse(self):
