@@ -67,6 +67,8 @@ typedef struct mfsgd_config {
 } mfsgd_config;
 
 #define MFSGD_FLAG_NO_GRAPH 1     /* launch eagerly instead of replaying a hipGraph            */
+#define MFSGD_FLAG_HOST_INGEST 4   /* bucket the ratings on the host even when a GPU is present     */
+#define MFSGD_FLAG_DEVICE_INGEST 8 /* ... on the GPU even for small rating sets (default: >= 2^20)  */
 #define MFSGD_FLAG_ROUND_LAUNCH 2 /* one kernel launch per round instead of the persistent      */
                                   /* epoch kernel (which hands item tiles between workgroups)   */
 
@@ -89,7 +91,7 @@ typedef struct mfsgd_schedule_info {
     int64_t sum_round_steps; /* sum over rounds of the slowest cell's critical path */
     double build_seconds;
     int32_t swapped;      /* 1: roles exchanged (users on the kernel's forwarding side): in the   */
-    int32_t reserved0;    /*    debug schedule arrays "p-side" rows are then ITEM rows            */
+    int32_t device_ingest; /* 1: degree histograms and bucket order were computed on the GPU      */
 } mfsgd_schedule_info;
 
 /* ---- lifetime ------------------------------------------------------------- */
@@ -108,7 +110,9 @@ const char* mfsgd_last_error(const mfsgd_handle* h);
  * Java: first half of train(int[] u, int[] i, float[] r, int epochs).
  * COO triples; 0 <= u < n_users, 0 <= i < n_items.  Buckets the ratings into
  * B x B (user block, item tile) cells per item partition and packs every cell
- * into conflict-free wave steps.  Host only; replaces any earlier ratings.   */
+ * into conflict-free wave steps.  Works without a GPU; with one (and >= 2^20
+ * ratings) the streaming passes -- degree histograms, bucket order -- run on it,
+ * with identical results.  Replaces any earlier ratings.                      */
 int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const float* r,
                       int64_t nnz);
 

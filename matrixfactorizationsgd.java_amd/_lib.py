@@ -46,7 +46,7 @@ class ScheduleInfo(C.Structure):
         ("sum_round_steps", C.c_int64),
         ("build_seconds", C.c_double),
         ("swapped", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("device_ingest", C.c_int32),
     ]
 
     def as_dict(self):
@@ -55,6 +55,8 @@ class ScheduleInfo(C.Structure):
 
 FLAG_NO_GRAPH = 1
 FLAG_ROUND_LAUNCH = 2
+FLAG_HOST_INGEST = 4
+FLAG_DEVICE_INGEST = 8
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)

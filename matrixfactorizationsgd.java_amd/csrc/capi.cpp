@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/mfsgd.h"
+#include "ingest.hpp"
 #include "jrandom.hpp"
 #include "kernels.hpp"
 #include "schedule.hpp"
@@ -427,7 +428,21 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
                                                           std::to_string(u[j]) + "," + std::to_string(i[j]) + ") out of range");
         const int G = h->n_parts;
         h->parts.resize((size_t)G);
+        // Ingestion (degree histograms, bucket order) runs on the GPU when there is one and the
+        // rating set is large enough to pay for the upload; the host loops are the fallback.
+        DeviceIngest ingest;
+        const bool want_dev = !(h->cfg.flags & MFSGD_FLAG_HOST_INGEST) &&
+                              ((h->cfg.flags & MFSGD_FLAG_DEVICE_INGEST) || nnz >= (int64_t)1 << 20);
+        if (want_dev) {
+            if (ensure_device(h) == MFSGD_OK) ingest = make_device_ingest(h->cfg.device);
+            else h->err.clear();  // no device: not an error for a host-side call
+        }
+        struct IngestGuard {
+            DeviceIngest& d;
+            ~IngestGuard() { destroy_device_ingest(d); }
+        } ingest_guard{ingest};
         SchedParams prm;
+        prm.ingest = ingest.ctx ? &ingest : nullptr;
         prm.U = h->cfg.n_users;
         prm.k = h->cfg.k;
         prm.lr = h->cfg.lr;
@@ -708,6 +723,7 @@ int mfsgd_get_schedule_info(const mfsgd_handle* h, int32_t part, mfsgd_schedule_
     out->sum_round_steps = s.sum_round_steps;
     out->build_seconds = s.build_seconds;
     out->swapped = h->parts[(size_t)part].swapped ? 1 : 0;
+    out->device_ingest = s.device_ingest ? 1 : 0;
     return MFSGD_OK;
 }
 

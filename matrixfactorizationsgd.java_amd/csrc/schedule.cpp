@@ -326,15 +326,27 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
 
     // ---- degrees and LPT partition into B*W fine bins -----------------------
     std::vector<int64_t> degu((size_t)U, 0), degi((size_t)I, 0);
-    for (int64_t j = 0; j < n; ++j) {
-        if (u[j] < 0 || u[j] >= U || i[j] < 0 || i[j] >= I) {
-            err = "set_ratings: index out of range at rating " + std::to_string(j);
-            return -1;
+    bool on_device = prm.ingest && prm.ingest->degrees && prm.ingest->bucket;
+    if (on_device) {
+        for (int64_t j = 0; j < n && on_device; ++j)
+            if (u[j] < 0 || u[j] >= U || i[j] < 0 || i[j] >= I) on_device = false;  // let the host loop report it
+        if (on_device && prm.ingest->degrees(prm.ingest->ctx, u, i, n, U, I, degu.data(), degi.data()) != 0) {
+            on_device = false;
+            std::fill(degu.begin(), degu.end(), 0);
+            std::fill(degi.begin(), degi.end(), 0);
         }
-        degu[(size_t)u[j]]++;
-        degi[(size_t)i[j]]++;
     }
-    lap("degrees");
+    if (!on_device) {
+        for (int64_t j = 0; j < n; ++j) {
+            if (u[j] < 0 || u[j] >= U || i[j] < 0 || i[j] >= I) {
+                err = "set_ratings: index out of range at rating " + std::to_string(j);
+                return -1;
+            }
+            degu[(size_t)u[j]]++;
+            degi[(size_t)i[j]]++;
+        }
+    }
+    lap(on_device ? "degrees (device)" : "degrees");
     std::vector<int32_t> ubin, ibin;
     lpt_assign(degu, B * W, ubin);
     lpt_assign(degi, B * W, ibin);
@@ -350,21 +362,24 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         const int s = (is - us + W) % W;
         return (((int64_t)ub * B + it) * W + s) * W + us;
     };
-    std::vector<int64_t> bkt((size_t)n);
-    for (int64_t j = 0; j < n; ++j) {
-        const int64_t b = bucket_of(j);
-        bkt[(size_t)j] = b;
-        bptr[(size_t)b + 1]++;
-    }
-    for (int64_t b = 0; b < nb; ++b) bptr[(size_t)b + 1] += bptr[(size_t)b];
     std::vector<int64_t> sorted((size_t)n);
-    {
+    if (on_device && prm.ingest->bucket(prm.ingest->ctx, u, i, n, ubin.data(), ibin.data(), U, I, B, W, bptr.data(),
+                                        sorted.data()) != 0) {
+        on_device = false;
+        std::fill(bptr.begin(), bptr.end(), 0);
+    }
+    if (!on_device) {
+        std::vector<int64_t> bkt((size_t)n);
+        for (int64_t j = 0; j < n; ++j) {
+            const int64_t b = bucket_of(j);
+            bkt[(size_t)j] = b;
+            bptr[(size_t)b + 1]++;
+        }
+        for (int64_t b = 0; b < nb; ++b) bptr[(size_t)b + 1] += bptr[(size_t)b];
         std::vector<int64_t> cur(bptr.begin(), bptr.end() - 1);
         for (int64_t j = 0; j < n; ++j) sorted[(size_t)cur[(size_t)bkt[(size_t)j]]++] = j;
     }
-    bkt.clear();
-    bkt.shrink_to_fit();
-    lap("bucket (counting sort)");
+    lap(on_device ? "bucket (device radix sort)" : "bucket (counting sort)");
 
     // ---- per-cell packing (parallel over cells) ------------------------------
     const int64_t ncell = (int64_t)B * B;
@@ -592,6 +607,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         return -1;
     }
     lap("concatenate + order");
+    out.device_ingest = on_device;
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return 0;
 }

@@ -24,6 +24,8 @@
 #include <string>
 #include <vector>
 
+#include "ingest.hpp"
+
 namespace mfsgd {
 
 struct Geometry {
@@ -75,6 +77,7 @@ struct SchedParams {
     int lds_budget = 160 * 1024 - 512;
     int n_cu = 256;
     int threads = 0;        // 0 = hardware_concurrency
+    const DeviceIngest* ingest = nullptr;  // optional: degrees and bucket order computed on the GPU
 };
 
 struct Schedule {
@@ -93,6 +96,7 @@ struct Schedule {
     int64_t total_steps = 0, total_rows = 0;
     int64_t max_cell_nnz = 0, max_cell_rows = 0, max_cell_steps = 0, sum_round_steps = 0;
     double build_seconds = 0;
+    bool device_ingest = false;  // degrees + bucket order came from the GPU
 };
 
 // u/i are row indices into P and into this partition's Q block; orig[j] is the

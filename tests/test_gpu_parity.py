@@ -205,6 +205,25 @@ def test_train_from_a_ratings_file(mf, oracle, tmp_path):
     _run(mf, oracle, d["n_users"], d["n_items"], 32, d["u"], d["i"], d["r"], epochs=2)
 
 
+def test_device_ingest_builds_the_same_schedule(mf):
+    """Degree histograms + bucket order on the GPU (ingest.hip) vs the host loops."""
+    from mfsgd_amd import _lib
+
+    for name, scale in (("cfg2_ml20m", 0.02), ("cfg1_ml100k", 1.0), ("cfg4_powerlaw", 0.0003)):
+        w = mf.synth.workload(name, scale)
+        got = []
+        for flags in (_lib.FLAG_HOST_INGEST, _lib.FLAG_DEVICE_INGEST):
+            with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 5, flags=flags) as m:
+                m.set_ratings(w["u"], w["i"], w["r"])
+                info = m.schedule_info()
+                assert info["device_ingest"] == (1 if flags == _lib.FLAG_DEVICE_INGEST else 0)
+                got.append((m.order()[0], m.debug_schedule(), info["blocks"]))
+        assert got[0][2] == got[1][2]
+        np.testing.assert_array_equal(got[0][0], got[1][0])
+        for a, b in zip(got[0][1], got[1][1]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_train_twice_and_new_ratings(mf, oracle):
     w = mf.synth.workload("cfg1_ml100k", scale=0.2)
     with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 8) as m:
