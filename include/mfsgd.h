@@ -135,6 +135,12 @@ int mfsgd_rmse(mfsgd_handle* h, double* out);
 /* Java: predict(int u, int i) / predict(int[] u, int[] i). */
 int mfsgd_predict(mfsgd_handle* h, const int32_t* u, const int32_t* i, float* out, int64_t n);
 
+/* Top-N scoring: for each of n_users users the topn items with the largest
+ * dot(P[u], Q[i]) -- the same bits mfsgd_predict() returns -- best first, ties by the
+ * smaller item index.  out_items / out_scores: n_users x topn, row-major.          */
+int mfsgd_recommend(mfsgd_handle* h, const int32_t* users, int32_t n_users, int32_t topn, int32_t* out_items,
+                    float* out_scores);
+
 /* Timed variant used by bench.py: runs `epochs` training passes bracketed by
  * HIP events on the handle's stream and returns the elapsed device time and
  * the number of sgd-round kernel launches inside it.  No RMSE pass.          */

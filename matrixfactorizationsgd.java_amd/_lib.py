@@ -78,6 +78,7 @@ SIGNATURES = {
     "mfsgd_train": (C.c_int, [_H, C.c_int32, _f64p]),
     "mfsgd_rmse": (C.c_int, [_H, _f64p]),
     "mfsgd_predict": (C.c_int, [_H, _i32p, _i32p, _f32p, C.c_int64]),
+    "mfsgd_recommend": (C.c_int, [_H, _i32p, C.c_int32, C.c_int32, _i32p, _f32p]),
     "mfsgd_train_timed": (C.c_int, [_H, C.c_int32, _f64p, _i64p]),
     "mfsgd_ratings_file_open": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(_H)]),
     "mfsgd_ratings_file_info": (C.c_int, [_H, _i64p, _i32p, _i32p]),

@@ -59,6 +59,14 @@ class MatrixFactorizationSGD {
         return out;
     }
 
+    // int[][] recommend(int[] users, int topN): best items per user, best first (row-major users x topN)
+    std::pair<std::vector<int32_t>, std::vector<float>> recommend(const std::vector<int32_t>& users, int topn) {
+        std::vector<int32_t> items(users.size() * (size_t)topn);
+        std::vector<float> scores(users.size() * (size_t)topn);
+        check(mfsgd_recommend(h_, users.data(), (int32_t)users.size(), topn, items.data(), scores.data()));
+        return {std::move(items), std::move(scores)};
+    }
+
     double rmse() {
         double out = 0.0;
         check(mfsgd_rmse(h_, &out));

@@ -692,6 +692,67 @@ int mfsgd_predict(mfsgd_handle* h, const int32_t* u, const int32_t* i, float* ou
     return MFSGD_OK;
 }
 
+int mfsgd_recommend(mfsgd_handle* h, const int32_t* users, int32_t n_users, int32_t topn, int32_t* out_items,
+                    float* out_scores) {
+    if (!h || n_users < 0 || topn < 1 || (n_users > 0 && (!users || !out_items || !out_scores)))
+        return fail(h, MFSGD_ERR_INVALID_ARG, "recommend: bad argument");
+    if (h->n_parts != 1) return fail(h, MFSGD_ERR_STATE, "recommend: single-partition handles only");
+    if (topn > h->cfg.n_items) return fail(h, MFSGD_ERR_INVALID_ARG, "recommend: topn exceeds the number of items");
+    for (int32_t j = 0; j < n_users; ++j)
+        if (users[j] < 0 || users[j] >= h->cfg.n_users)
+            return fail(h, MFSGD_ERR_INVALID_ARG, "recommend: user " + std::to_string(j) + " out of range");
+    if (n_users == 0) return MFSGD_OK;
+    int rc = factors_to_device(h);
+    if (rc) return rc;
+    const int32_t I = h->cfg.n_items;
+    // users per batch: about 64 M scores at a time
+    int batch = (int)std::max<int64_t>(1, std::min<int64_t>(n_users, ((int64_t)64 << 20) / std::max(1, I)));
+    batch = std::min(batch, 65535);
+    DevBuf d_users, s_in, s_out, id_in, id_out, d_off, o_s, o_i;
+    void* temp = nullptr;
+    size_t temp_bytes = 0;
+    auto cleanup = [&]() {
+        d_users.release(); s_in.release(); s_out.release(); id_in.release(); id_out.release(); d_off.release();
+        o_s.release(); o_i.release();
+        if (temp) (void)hipFree(temp);
+    };
+    const size_t cells = (size_t)batch * (size_t)I;
+    rc = dev_alloc(h, d_users, sizeof(int32_t) * (size_t)batch);
+    if (!rc) rc = dev_alloc(h, s_in, 4 * cells);
+    if (!rc) rc = dev_alloc(h, s_out, 4 * cells);
+    if (!rc) rc = dev_alloc(h, id_in, 4 * cells);
+    if (!rc) rc = dev_alloc(h, id_out, 4 * cells);
+    if (!rc) rc = dev_alloc(h, d_off, sizeof(long long) * ((size_t)batch + 1));
+    if (!rc) rc = dev_alloc(h, o_s, 4 * (size_t)batch * topn);
+    if (!rc) rc = dev_alloc(h, o_i, 4 * (size_t)batch * topn);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipSuccess;
+    for (int32_t done = 0; done < n_users && e == hipSuccess; done += batch) {
+        const int nb = std::min<int32_t>(batch, n_users - done);
+        e = hipMemcpyAsync(d_users.p, users + done, sizeof(int32_t) * (size_t)nb, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess)
+            e = recommend_batch(h->geo.L, static_cast<const float*>(h->dP.p), static_cast<const float*>(h->dQ.p),
+                                static_cast<const int32_t*>(d_users.p), nb, I, topn, static_cast<float*>(s_in.p),
+                                static_cast<float*>(s_out.p), static_cast<int32_t*>(id_in.p), static_cast<int32_t*>(id_out.p),
+                                static_cast<long long*>(d_off.p), temp, temp_bytes, static_cast<float*>(o_s.p),
+                                static_cast<int32_t*>(o_i.p), h->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(out_scores + (size_t)done * topn, o_s.p, 4 * (size_t)nb * topn, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(out_items + (size_t)done * topn, o_i.p, 4 * (size_t)nb * topn, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    cleanup();
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(h, e == hipErrorOutOfMemory ? MFSGD_ERR_OOM : MFSGD_ERR_HIP, std::string("recommend: ") + hipGetErrorString(e));
+    }
+    return MFSGD_OK;
+}
+
 int mfsgd_get_dims(const mfsgd_handle* h, int32_t* n_users, int32_t* n_items, int32_t* k) {
     if (!h) return MFSGD_ERR_INVALID_ARG;
     if (n_users) *n_users = h->cfg.n_users;

@@ -51,6 +51,16 @@ public final class MatrixFactorizationSGD implements AutoCloseable {
         return out;
     }
 
+    /** The topN best items of each user, best first (ties: smaller item index); scores as predict() gives them. */
+    public int[][] recommend(int[] users, int topN) {
+        int[] items = new int[users.length * topN];
+        float[] scores = new float[users.length * topN];
+        nativeRecommend(handle, users, topN, items, scores);
+        int[][] out = new int[users.length][];
+        for (int a = 0; a < users.length; a++) out[a] = java.util.Arrays.copyOfRange(items, a * topN, (a + 1) * topN);
+        return out;
+    }
+
     public double rmse() {
         return nativeRmse(handle);
     }
@@ -86,4 +96,5 @@ public final class MatrixFactorizationSGD implements AutoCloseable {
     private static native void nativeTrain(long h, int epochs, double[] rmsePerEpoch);
     private static native double nativeRmse(long h);
     private static native void nativePredict(long h, int[] u, int[] i, float[] out);
+    private static native void nativeRecommend(long h, int[] users, int topN, int[] items, float[] scores);
 }

@@ -125,4 +125,21 @@ JNIEXPORT void JNICALL Java_MatrixFactorizationSGD_nativePredict(JNIEnv* env, jc
     throw_status(env, H(h), rc);
 }
 
+JNIEXPORT void JNICALL Java_MatrixFactorizationSGD_nativeRecommend(JNIEnv* env, jclass, jlong h, jintArray users,
+                                                                   jint topn, jintArray items, jfloatArray scores) {
+    const jsize n = env->GetArrayLength(users);
+    jint* cu = env->GetIntArrayElements(users, nullptr);
+    int32_t* ci = n > 0 ? new (std::nothrow) int32_t[(size_t)n * topn] : nullptr;
+    float* cs = n > 0 ? new (std::nothrow) float[(size_t)n * topn] : nullptr;
+    const int rc = mfsgd_recommend(H(h), reinterpret_cast<const int32_t*>(cu), n, topn, ci, cs);
+    env->ReleaseIntArrayElements(users, cu, JNI_ABORT);
+    if (rc == MFSGD_OK && ci && cs) {
+        env->SetIntArrayRegion(items, 0, n * topn, reinterpret_cast<const jint*>(ci));
+        env->SetFloatArrayRegion(scores, 0, n * topn, cs);
+    }
+    delete[] ci;
+    delete[] cs;
+    throw_status(env, H(h), rc);
+}
+
 }  // extern "C"

@@ -166,6 +166,15 @@ class MatrixFactorizationSGD:
                                             _p(out, C.c_float), uu.size))
         return float(out[0]) if scalar else out
 
+    def recommend(self, users, topn):
+        """(items, scores), each [len(users), topn]: best items per user, best first."""
+        uu = _i32(np.atleast_1d(users))
+        items = np.empty((uu.size, int(topn)), np.int32)
+        scores = np.empty((uu.size, int(topn)), np.float32)
+        self._check(self._lib.mfsgd_recommend(self._handle(), _p(uu, C.c_int32), uu.size, int(topn),
+                                              _p(items, C.c_int32), _p(scores, C.c_float)))
+        return items, scores
+
     # -- schedule introspection (tests, bench) -----------------------------------
     def schedule_info(self, part=0):
         info = _lib.ScheduleInfo()

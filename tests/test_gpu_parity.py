@@ -191,6 +191,27 @@ def test_predict_and_set_factors(mf, oracle):
     np.testing.assert_array_equal(Q2, Q)
 
 
+@pytest.mark.parametrize("k", [8, 64, 100])
+def test_recommend_topn_equals_sorted_predictions(mf, oracle, k):
+    rng = np.random.default_rng(k)
+    U, I, topn = 50, 700, 25
+    P = rng.standard_normal((U, k)).astype(np.float32)
+    Q = rng.standard_normal((I, k)).astype(np.float32)
+    Q[5] = Q[9]  # exact ties: the smaller item index must come first
+    users = np.array([0, 7, 7, 49, 13], np.int32)
+    with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 1) as m:
+        m.set_factors(P, Q)
+        items, scores = m.recommend(users, topn)
+        with pytest.raises(mf.MfsgdError):
+            m.recommend(users, I + 1)
+    allitems = np.arange(I, dtype=np.int32)
+    for row, u in enumerate(users):
+        s = oracle.predict(P, Q, np.full(I, u, np.int32), allitems)
+        order = np.lexsort((allitems, -s.astype(np.float64)))[:topn]
+        np.testing.assert_array_equal(items[row], order)
+        np.testing.assert_array_equal(scores[row], s[order])
+
+
 def test_train_from_a_ratings_file(mf, oracle, tmp_path):
     rng = np.random.default_rng(12)
     U, I, n = 400, 300, 9000
