@@ -80,3 +80,30 @@ class OracleBackend:
 
     def synchronize(self):
         pass
+
+
+def fuzz_cases(n_cases, seed=2024, max_ratings=2500):
+    """Random small problems: sizes, density, skew, k and explicit geometry all drawn at random."""
+    rng = np.random.default_rng(seed)
+    for _ in range(n_cases):
+        U = int(rng.integers(1, 120))
+        I = int(rng.integers(1, 120))
+        n = int(min(max_ratings, max(1, rng.integers(1, U * I + 1))))
+        if rng.random() < 0.5:  # skewed: a few heavy rows
+            wu = 1.0 / (np.arange(U) + 1.0) ** rng.uniform(0.0, 1.5)
+            wi = 1.0 / (np.arange(I) + 1.0) ** rng.uniform(0.0, 1.5)
+            u = rng.choice(U, n, p=wu / wu.sum())
+            i = rng.choice(I, n, p=wi / wi.sum())
+        else:
+            u = rng.integers(0, U, n)
+            i = rng.integers(0, I, n)
+        if rng.random() < 0.7:  # usually de-duplicated, sometimes with repeated pairs
+            key = np.unique(u.astype(np.int64) * I + i)
+            key = rng.permutation(key)
+            u, i = key // I, key % I
+        r = (rng.standard_normal(u.size) * 2 + 3).astype(np.float32)
+        k = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 20, 32, 33, 64, 96, 128, 130, 256]))
+        W = int(rng.choice([0, 1, 2, 4, 8]))
+        B = int(rng.choice([0, 0, 1, 2, 3, 5]))
+        yield dict(U=U, I=I, k=k, u=u.astype(np.int32), i=i.astype(np.int32), r=r, blocks=B, waves=W,
+                   lr=float(rng.choice([0.01, 0.05])), lam=float(rng.choice([0.0, 0.05])))

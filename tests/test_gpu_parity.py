@@ -172,6 +172,21 @@ def test_large_values_and_zero_lambda(mf, oracle):
     _run(mf, oracle, U, I, 32, key // I, key % I, rng.standard_normal(n) * 50, epochs=2, lr=0.001, lam=0.0)
 
 
+def test_fuzz_random_problems(mf, oracle):
+    from tests.dsgd_common import fuzz_cases
+
+    ok = 0
+    for c in fuzz_cases(120, seed=77):
+        try:
+            _run(mf, oracle, c["U"], c["I"], c["k"], c["u"], c["i"], c["r"], epochs=2, lr=c["lr"], lam=c["lam"],
+                 blocks=c["blocks"], waves=c["waves"])
+        except mf.MfsgdError as e:
+            assert e.code == -7, e
+            continue
+        ok += 1
+    assert ok >= 90
+
+
 # ---- predict / factors / repeated training ------------------------------------------
 def test_predict_and_set_factors(mf, oracle):
     rng = np.random.default_rng(4)

@@ -134,3 +134,29 @@ def test_partitioned_schedules_cover_everything(mf, oracle):
             assert oracle.check_block_schedule(w["u"][sel], w["i"][sel] // G, w["U"], m.part_rows(part),
                                                np.arange(sel.size, dtype=np.int64), cell_ptr, info["rounds"], info["blocks"]) == 0
         assert seen.all()
+
+
+def test_fuzz_schedules_replay_exactly(mf, oracle):
+    from tests.dsgd_common import fuzz_cases
+
+    ok = 0
+    for c in fuzz_cases(40, max_ratings=1200):
+        try:
+            with mf.MatrixFactorizationSGD(c["U"], c["I"], c["k"], c["lr"], c["lam"], 3, blocks=c["blocks"], waves=c["waves"]) as m:
+                m.set_ratings(c["u"], c["i"], c["r"])
+                info = m.schedule_info()
+                order, cell_ptr = m.order()
+                sched = m.debug_schedule()
+        except mf.MfsgdError as e:
+            assert e.code == -7, e  # an explicit B too small for the LDS image is a legal refusal
+            continue
+        assert oracle.check_block_schedule(c["u"], c["i"], c["U"], c["I"], order, cell_ptr, info["rounds"], info["blocks"]) == 0
+        P, Q = oracle.init_factors(c["U"], c["I"], c["k"], 3)
+        Pe, Qe = P.copy(), Q.copy()
+        oracle.sgd_pass_ordered(P, Q, c["u"], c["i"], c["r"], order, c["lr"], c["lam"])
+        a, b = (Qe, Pe) if info["swapped"] else (Pe, Qe)
+        replay_epoch(oracle, a, b, c["k"], c["lr"], c["lam"], sched, info["blocks"], info["waves"], info["slots"], info["group_lanes"])
+        np.testing.assert_array_equal(Pe, P)
+        np.testing.assert_array_equal(Qe, Q)
+        ok += 1
+    assert ok >= 30

@@ -18,10 +18,12 @@
 #endif
 #if V == 3 || V == 5
 #define SCALE(x) ""
+#elif V == 12
+#define SCALE(x) x
 #else
 #define SCALE(x) x
 #endif
-#if V == 4 || V == 5
+#if V == 4 || V == 5 || V == 12
 #define PUPD(x) ""
 #else
 #define PUPD(x) x
@@ -60,8 +62,12 @@ __global__ void k(unsigned long long* cyc, float* out, int iters, float lr) {
         LDS("ds_read_b128 v[108:111], v113\n\t")
         SCALE("v_pk_mul_f32 v[124:125], v[116:117], v[102:103] op_sel:[1,0]\n\t")
         DPP("quad_perm:[2,3,0,1]")
+#if V != 12
         SCALE("v_pk_mul_f32 v[126:127], v[116:117], v[104:105] op_sel:[1,0]\n\t")
         SCALE("v_pk_mul_f32 v[128:129], v[116:117], v[106:107] op_sel:[1,0]\n\t")
+#else
+        "s_nop 1\n\t"
+#endif
         DPP("row_half_mirror")
 #if V == 7
         "ds_read_b128 v[144:147], v138 offset:64\n\t"
@@ -79,6 +85,11 @@ __global__ void k(unsigned long long* cyc, float* out, int iters, float lr) {
         "v_pk_fma_f32 v[102:103], v[130:131], v[106:107], v[124:125] op_sel_hi:[0,1,1]\n\t"
         PUPD("v_pk_fma_f32 v[134:135], v[130:131], v[100:101], v[126:127] op_sel_hi:[0,1,1]\n\t")
         PUPD("v_pk_fma_f32 v[136:137], v[130:131], v[102:103], v[128:129] op_sel_hi:[0,1,1]\n\t")
+#if V == 12
+        "s_mov_b64 exec, %[mask]\n\t"
+        "ds_write_b32 v138, v130 offset:2048\n\t"
+        "s_mov_b64 exec, -1\n\t"
+#endif
         "s_sub_u32 %[n], %[n], 1\n\t"
         "s_cmp_lg_u32 %[n], 0\n\t"
         LDS("v_mov_b32 v104, v108\n\tv_mov_b32 v105, v109\n\tv_mov_b32 v106, v110\n\tv_mov_b32 v107, v111\n\t")
@@ -95,7 +106,7 @@ __global__ void k(unsigned long long* cyc, float* out, int iters, float lr) {
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_mov_b32 %[o], v100\n\t"
         : [n] "+s"(n), [o] "=v"(o)
-        : [ea] "v"(ea), [rb] "v"(lane16), [lr] "s"(lr)
+        : [ea] "v"(ea), [rb] "v"(lane16), [lr] "s"(lr), [mask] "s"(0x0001000100010001ull)
         : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v144", "v145", "v146", "v147");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     out[threadIdx.x] = o;
@@ -105,7 +116,7 @@ int main() {
     unsigned long long* c; float* o; hipMalloc(&c, 8); hipMalloc(&o, 256);
     const int iters = 4096; unsigned long long h = 0, best = ~0ull;
     for (int r = 0; r < 5; ++r) { hipLaunchKernelGGL(k, dim3(1), dim3(64), 65536, 0, c, o, iters, 0.01f); hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost); if (h < best) best = h; }
-    const char* names[] = {"full step", "DPP adds -> s_nop", "no LDS ops (+4 movs gone)", "no scale pk_mul x4", "no p' update + store", "pure dependent chain", "no address calc", "entry: one b128 read", "entry: one b64 read", "store as 2 x b64", "store as 4 x b32", "store as write2_b64"};
+    const char* names[] = {"full step", "DPP adds -> s_nop", "no LDS ops (+4 movs gone)", "no scale pk_mul x4", "no p' update + store", "pure dependent chain", "no address calc", "entry: one b128 read", "entry: one b64 read", "store as 2 x b64", "store as 4 x b32", "store as write2_b64", "chain wave of a two-wave split"};
     printf("V=%d %-28s %7.1f cycles/step\n", V, names[V], (double)best / iters);
     return 0;
 }
