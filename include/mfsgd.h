@@ -188,6 +188,13 @@ int mfsgd_debug_schedule_sizes(const mfsgd_handle* h, int32_t part, int64_t* n_c
 int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cells, uint32_t* rows,
                              uint32_t* subs, uint32_t* entries);
 
+/* Diagnostic (not part of the Java surface): runs ONE epoch with the persistent kernel and
+ * returns, per workgroup, 8 words: shader cycles wave 0 spent in (0) draining its previous
+ * stores and issuing prefetch + own-row gather, (1) waiting for the tile, (2) the barrier after
+ * it, (3) the tile gather, (4) the ratings, (5) storing + publishing the tile, (6) storing its
+ * own rows; word 7 unused.  out must hold blocks x 8 words.  It DOES apply the epoch.           */
+int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgroups);
+
 /* Diagnostic (not part of the Java surface): runs training round `round` once with
  * phase stamps; out receives blocks x 6 values per workgroup: shader-clock at
  * start, after gather, after the rating steps, after scatter, then the 100 MHz

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mfsgd_debug_schedule_sizes": (C.c_int, [_H, C.c_int32, _i64p, _i64p, _i64p, _i64p]),
     "mfsgd_debug_get_schedule": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mfsgd_debug_epoch_profile": (C.c_int, [_H, C.POINTER(C.c_uint64), _i32p]),
     "mfsgd_debug_round_stamps": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     "mfsgd_part_rows": (C.c_int, [_H, C.c_int32, _i32p]),
     "mfsgd_part_init_q": (C.c_int, [_H, C.c_int32, C.c_int64, C.c_int64, _f32p]),

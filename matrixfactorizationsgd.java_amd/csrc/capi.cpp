@@ -824,6 +824,29 @@ int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cell
     return MFSGD_OK;
 }
 
+int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgroups) {
+    if (!h || !out || !n_workgroups) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_epoch_profile: null argument");
+    if (h->n_parts != 1) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_epoch_profile: single-partition handles only");
+    int rc = prepare_compute(h);
+    if (rc) return rc;
+    Part& p = h->parts[0];
+    if ((rc = probe_persistent(h, p))) return rc;
+    if (p.persistent_np <= 0) return fail(h, MFSGD_ERR_STATE, "debug_epoch_profile: persistent kernel not in use");
+    const size_t words = (size_t)p.persistent_np * 8;
+    if ((rc = dev_alloc(h, p.d_sse_partial, std::max(words * sizeof(uint64_t), sizeof(double) * (size_t)p.sched.B * p.sched.B)))) return rc;
+    CellLaunch a = make_launch(h, p, static_cast<float*>(h->dQ.p));
+    a.grid = p.persistent_np;
+    a.diag = true;
+    a.sse_partial = static_cast<double*>(p.d_sse_partial.p);
+    HIPCHK(h, hipMemsetAsync(p.d_sse_partial.p, 0, words * sizeof(uint64_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(p.d_sync.p, 0, sync_bytes(p) - sizeof(unsigned) * 4, h->stream));
+    HIPCHK(h, launch_epoch_persistent(h->geo.L, p.sched.W, a, p.sched.B, static_cast<unsigned*>(p.d_sync.p), abort_word(p), h->stream));
+    HIPCHK(h, hipMemcpyAsync(out, p.d_sse_partial.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *n_workgroups = p.persistent_np;
+    return check_abort(h, p);
+}
+
 int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint64_t* out) {
     if (!h || !out) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_round_stamps: null argument");
     if (h->n_parts != 1 || part != 0) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_round_stamps: single-partition handles only");

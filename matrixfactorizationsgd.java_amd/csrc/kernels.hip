@@ -221,6 +221,7 @@ struct Cell {
     int tid, lane, wave, g, lig;
     unsigned laneoff;
     int nu, nrows, n_steps;
+    bool critical;  // the cell carries a long per-row chain (scheduler flag)
     unsigned char* lrows;
     uint4* lent;
     uint2* lsub;
@@ -237,7 +238,8 @@ struct Cell {
     __device__ __forceinline__ void bind(const CellDesc& cd, unsigned char* smem, int buf, int sched_cap) {
         nu = cd.nu;
         nrows = (int)cd.nu + (int)cd.ni;
-        n_steps = (int)cd.n_steps;
+        n_steps = (int)(cd.n_steps & 0x7FFFFFFFu);
+        critical = (cd.n_steps >> 31) != 0;
         lrows = smem + CTL + 2 * (size_t)sched_cap;
         lent = reinterpret_cast<uint4*>(smem + CTL + (size_t)buf * sched_cap);
         lsub = reinterpret_cast<uint2*>(lent + (size_t)n_steps * G);
@@ -259,7 +261,7 @@ struct Cell {
                                                       const Entry* __restrict__ entries) {
         unsigned char* const dst = smem + CTL + (size_t)buf * sched_cap;
         const int nn = (int)nd.nu + (int)nd.ni;
-        const int ent_bytes = (int)nd.n_steps * G * 16;
+        const int ent_bytes = (int)(nd.n_steps & 0x7FFFFFFFu) * G * 16;
         const int sub_bytes = W * W * 8;
         const int ids_bytes = (nn * 4 + 15) & ~15;
         auto copy = [&](const unsigned char* src, unsigned char* d, int bytes) {
@@ -293,8 +295,28 @@ struct Cell {
     // bytes); the source address is per lane, so it is a row gather.  Issues every
     // load of the wave back to back and does NOT wait: caller does vmcnt(0) + barrier.
     __device__ __forceinline__ void gather(const float* __restrict__ P, const float* __restrict__ Q, int lo, int hi) {
+        constexpr int UNR = 4;  // row ids of UNR instructions are fetched before any of them is issued
         const int first = (lo / G) * G;  // keep wave instructions aligned to G-slot groups
-        for (int s0 = first + wave * G; s0 < hi; s0 += W * G) {
+        int s0 = first + wave * G;
+        for (; s0 + (UNR - 1) * W * G < hi; s0 += UNR * W * G) {
+            uint32_t rid[UNR];
+            bool in[UNR];
+#pragma unroll
+            for (int x = 0; x < UNR; ++x) {
+                const int sx = s0 + x * W * G + g;
+                in[x] = sx >= lo && sx < hi;
+                rid[x] = lids[in[x] ? sx : lo];
+            }
+#pragma unroll
+            for (int x = 0; x < UNR; ++x) {
+                const int sb = s0 + x * W * G;
+                if (in[x]) {
+                    const float* src = (sb + g < nu ? P : Q) + (size_t)rid[x] * KP + lig * 4;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lrows + (size_t)sb * ROWB), 16, 0, 0);
+                }
+            }
+        }
+        for (; s0 < hi; s0 += W * G) {
             const int sx = s0 + g;
             if (sx >= lo && sx < hi) {
                 const uint32_t rid = lids[sx];
@@ -308,17 +330,31 @@ struct Cell {
     // workgroup will read inside the same launch (cdna guide, Guideline 16, form R1).
     template <bool WT>
     __device__ __forceinline__ void scatter(float* __restrict__ P, float* __restrict__ Q, int lo, int hi) {
-        for (int s = lo + wave * G + g; s < hi; s += W * G) {
-            const uint32_t rid = lids[s];
+        constexpr int UNR = 4;
+        auto put = [&](int s, uint32_t rid, const float4 v) {
             float* dst = (s < nu ? P : Q) + (size_t)rid * KP + lig * 4;
-            const float4 v = lds_ld(lrows, (unsigned)(s * ROWB) + laneoff);
             if constexpr (WT) {
                 const f32x4 vv = {v.x, v.y, v.z, v.w};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
+                // hipcc pads nothing inside asm: a VALU write of a >64-bit store operand needs a wait
+                // state before the store reads it, and the operands must not be rewritten right after
+                asm volatile("s_nop 1\n\tglobal_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
             } else {
                 *reinterpret_cast<float4*>(dst) = v;
             }
+        };
+        int s = lo + wave * G + g;
+        for (; s + (UNR - 1) * W * G < hi; s += UNR * W * G) {
+            uint32_t rid[UNR];
+            float4 v[UNR];
+#pragma unroll
+            for (int x = 0; x < UNR; ++x) {
+                rid[x] = lids[s + x * W * G];
+                v[x] = lds_ld(lrows, (unsigned)((s + x * W * G) * ROWB) + laneoff);
+            }
+#pragma unroll
+            for (int x = 0; x < UNR; ++x) put(s + x * W * G, rid[x], v[x]);
         }
+        for (; s < hi; s += W * G) put(s, lids[s], lds_ld(lrows, (unsigned)(s * ROWB) + laneoff));
     }
 
     // ---- apply the ratings out of LDS ------------------------------------------
@@ -566,7 +602,8 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
                                          const SubDesc* __restrict__ subs, const Entry* __restrict__ entries,
                                          const int B, const int n_rounds, const float lr, const float c,
                                          unsigned* __restrict__ done, unsigned* __restrict__ abort_word,
-                                         const int sched_cap, const int wg, const int NP) {
+                                         const int sched_cap, const int wg, const int NP,
+                                         unsigned long long* __restrict__ prof) {
     using gu32 = __attribute__((address_space(1))) unsigned;
     volatile unsigned* const ctl = reinterpret_cast<volatile unsigned*>(smem);  // [0] = abort broadcast
     Cell<L, W> cx;
@@ -597,9 +634,20 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();
 
+    // optional phase accounting (diagnostic launches only): shader cycles of wave 0 per phase
+    unsigned long long pacc[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pt = 0;
+    auto mark = [&](int k) {
+        if (prof) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            pacc[k] += now - pt;
+            pt = now;
+        }
+    };
+    if (prof) pt = __builtin_amdgcn_s_memtime();
+
     for (; R < n_rounds;) {
         CellDesc cd2 = cd1;
-        if (R2 < n_rounds) cd2 = cells[cell_of(R2, b2)];  // used two iterations from now
         cx.bind(cd, smem, buf, sched_cap);
         const bool work = cx.nrows != 0;  // uniform over the workgroup
         cx.zero_idle_rows();
@@ -607,6 +655,7 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (R1 < n_rounds) cx.prefetch_schedule(cd1, cell_of(R1, b1), smem, buf ^ 1, sched_cap, rows, subs, entries);
         if (work) cx.gather(P, Q, 0, cx.nu);  // own rows: no dependency on other workgroups
+        mark(0);  // drain of the previous P stores + issue of the prefetch and the P gather
         if (R > 0) {
             // wait until block b + 1 has finished round R - 1 (it held our tile)
             if (cx.tid == 0) {
@@ -627,14 +676,21 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
+        mark(1);  // waiting for the tile (wave 0) 
         wg_barrier();
+        mark(2);  // the other waves' arrival
         if (ctl[0] != 0) return;  // uniform: some workgroup timed out
+        // descriptor used two iterations from now: issued here so that no wait of this
+        // iteration's latency-critical part (the drain above, the tile poll) sits behind it
+        if (R2 < n_rounds) cd2 = cells[cell_of(R2, b2)];
         if (work) {
             cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows (and the prefetched schedule) have landed
             wg_barrier();
+            mark(3);  // tile rows (and own rows, and the next schedule) landed
             double acc = 0.0;
             cx.template apply<true>(lr, c, acc);  // ends with a workgroup barrier
+            mark(4);  // the ratings
             cx.template scatter<true>(P, Q, cx.nu, cx.nrows);
         }
         // publish the tile: every storing wave drains, then one lane signals
@@ -643,6 +699,7 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         if (cx.tid == 0)
             __hip_atomic_store((gu32*)(done + (size_t)b * kFlagStride), (unsigned)(R + 1), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+        mark(5);  // tile rows stored write-through, drained, flag published
         if (work) cx.template scatter<false>(P, Q, 0, cx.nu);
         // The rows image and this schedule buffer are reused from here on: their LDS reads (the
         // scatter above) are complete once every wave has passed this barrier.  The next
@@ -656,7 +713,10 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         R1 = R2;
         b1 = b2;
         advance(R2, b2);
+        mark(6);  // own rows stored (not drained), end barrier
     }
+    if (prof && cx.tid == 0)
+        for (int k = 0; k < 7; ++k) prof[(size_t)wg * 8 + k] = pacc[k];
 }
 
 template <int L, int W>
@@ -665,10 +725,10 @@ epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __res
              const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs,
              const Entry* __restrict__ entries, const int B, const int n_rounds, const float lr,
              const float c, unsigned* __restrict__ done, unsigned* __restrict__ abort_word,
-             const int sched_cap) {
+             const int sched_cap, unsigned long long* __restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     run_ring<L, W>(smem, P, Q, cells, rows, subs, entries, B, n_rounds, lr, c, done, abort_word, sched_cap,
-                   (int)blockIdx.x, (int)gridDim.x);
+                   (int)blockIdx.x, (int)gridDim.x, prof);
 }
 
 // Fixed-order reduction of the per-cell partial sums (one workgroup).
@@ -743,7 +803,8 @@ hipError_t epoch_LW(int what, const CellLaunch& a, int n_rounds, unsigned* done,
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, 64 * W, (size_t)a.lds_bytes);
     }
     hipLaunchKernelGGL((epoch_kernel<L, W>), dim3((unsigned)a.grid), dim3(64 * W), (size_t)a.lds_bytes, st, a.P, a.Q,
-                       a.cells, a.rows, a.subs, a.entries, a.B, n_rounds, a.lr, a.c, done, abort_word, a.sched_cap);
+                       a.cells, a.rows, a.subs, a.entries, a.B, n_rounds, a.lr, a.c, done, abort_word, a.sched_cap,
+                       reinterpret_cast<unsigned long long*>(a.diag ? a.sse_partial : nullptr));
     return hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ struct CellLaunch {
     float lr;
     float c;         // 1 - lr*lambda
     double* sse_partial;
-    bool diag = false;  // training round with in-kernel phase stamps written to sse_partial (u64 x 4 per workgroup)
+    bool diag = false;  // diagnostic launch: in-kernel cycle stamps are written to sse_partial (as u64 words)
 };
 
 // One training round (train = true) or the SSE pass over every cell.

@@ -72,6 +72,7 @@ struct CellOut {
     std::vector<int64_t> order;
     uint32_t nu = 0, ni = 0, n_steps = 0;
     int64_t crit = 0;
+    bool has_run = false;
 };
 
 struct Scratch {
@@ -486,6 +487,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                         if (!failed.exchange(1)) fail_msg = "lds: sub-cell has more than 65535 steps";
                         break;
                     }
+                    if (nr > 0) o.has_run = true;
                     o.subs[(size_t)(s * W + w)] = SubDesc{stepcur, ns | (nr << 16)};
                     stepcur += ns + nr;
                     smax = std::max(smax, ns + nr);
@@ -532,7 +534,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         CellDesc d;
         d.row_off = (uint32_t)tot_rows;
         d.ent_off = (uint32_t)tot_steps;
-        d.n_steps = o.n_steps;
+        d.n_steps = o.n_steps | (o.has_run ? kCellCritical : 0u);
         d.nu = (uint16_t)o.nu;
         d.ni = (uint16_t)o.ni;
         out.cells[(size_t)c] = d;

@@ -46,11 +46,13 @@ int64_t rows_bytes_for(const Geometry& geo, int nrows);
 struct CellDesc {
     uint32_t row_off;  // first entry of this cell in rows[]
     uint32_t ent_off;  // first step of this cell (entries index = step * G + slot)
-    uint32_t n_steps;  // steps over all sub-cells
+    uint32_t n_steps;  // steps over all sub-cells; bit 31: latency-critical cell (it carries a long
+                       // per-row chain): the persistent kernel publishes its tile before anything else
     uint16_t nu;       // distinct users  -> LDS slots [0, nu)
     uint16_t ni;       // distinct items  -> LDS slots [nu, nu + ni)
 };
 static_assert(sizeof(CellDesc) == 16, "CellDesc layout");
+constexpr uint32_t kCellCritical = 0x80000000u;
 
 struct SubDesc {
     uint32_t off;  // first step, relative to the cell's first step

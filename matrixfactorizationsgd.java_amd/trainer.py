@@ -203,6 +203,14 @@ class MatrixFactorizationSGD:
                                                        _p(entries, C.c_uint32)))
         return cells, rows, subs, entries
 
+    def debug_epoch_profile(self):
+        """[workgroups, 7] shader cycles per phase of one persistent epoch (diagnostic)."""
+        info = self.schedule_info()
+        out = np.zeros(info["blocks"] * 8, np.uint64)
+        n = C.c_int32()
+        self._check(self._lib.mfsgd_debug_epoch_profile(self._handle(), _p(out, C.c_uint64), C.byref(n)))
+        return out[: n.value * 8].reshape(n.value, 8)[:, :7]
+
     def debug_round_stamps(self, rnd):
         """[blocks, 6] stamps of one training round (diagnostic): 4 shader-clock phase
         stamps, then the 100 MHz constant clock at start and end."""

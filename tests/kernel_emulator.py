@@ -18,6 +18,7 @@ def replay_epoch(oracle, P, Q, k, lr, lam, sched, B, W, G, L):
         for b in range(B):
             cell = b * B + (b + rd) % B
             row_off, ent_off, n_steps, nuni = (int(v) for v in cells[cell])
+            n_steps &= 0x7FFFFFFF  # bit 31: "latency-critical cell" hint for the persistent kernel
             nu, ni = nuni & 0xFFFF, nuni >> 16
             nrows = nu + ni
             if nrows == 0:
