@@ -287,8 +287,15 @@ int check_abort(mfsgd_handle* h, Part& p) {
 
 int launch_sse(mfsgd_handle* h, Part& p, const float* Q, hipStream_t st) {
     CellLaunch a = make_launch(h, p, const_cast<float*>(Q));
-    a.grid = p.sched.B * p.sched.B;
-    HIPCHK(h, launch_cell(false, h->geo.L, p.sched.W, a, st));
+    const int n_cells = p.sched.B * p.sched.B;
+    if (h->cfg.flags & MFSGD_FLAG_ROUND_LAUNCH) {  // reference form: one workgroup per cell
+        a.grid = n_cells;
+        HIPCHK(h, launch_cell(false, h->geo.L, p.sched.W, a, st));
+    } else {
+        const int per_cu = std::max(1, std::min(4, (160 * 1024) / std::max(1, p.sched.lds_bytes)));
+        a.grid = std::min(n_cells, per_cu * std::max(1, h->n_cu));
+        HIPCHK(h, launch_sse_persistent(h->geo.L, p.sched.W, a, n_cells, st));
+    }
     HIPCHK(h, launch_reduce_sse(a.sse_partial, (int64_t)a.grid, static_cast<double*>(p.d_sse_out.p), st));
     return MFSGD_OK;
 }

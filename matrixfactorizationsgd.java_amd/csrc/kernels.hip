@@ -731,6 +731,61 @@ epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __res
                    (int)blockIdx.x, (int)gridDim.x, prof);
 }
 
+// Sum of squared errors, persistent form: gridDim.x workgroups walk the B*B cells with a stride,
+// the next cell's schedule prefetched (LDS-DMA) while the current one is applied; no writes.
+// One fp64 partial per workgroup (fixed order inside it), reduced by reduce_sse_kernel.
+template <int L, int W>
+__global__ void __launch_bounds__(64 * W)
+sse_kernel(const float* __restrict__ P, const float* __restrict__ Q, const CellDesc* __restrict__ cells,
+           const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs, const Entry* __restrict__ entries,
+           const int n_cells, double* __restrict__ sse_partial, const int sched_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Cell<L, W> cx;
+    cx.init_thread();
+    const int stride = (int)gridDim.x;
+    int c = (int)blockIdx.x;
+    double acc = 0.0;
+    if (c < n_cells) {
+        CellDesc cd = cells[c];
+        CellDesc cd1 = c + stride < n_cells ? cells[c + stride] : cd;
+        int buf = 0;
+        cx.bind(cd, smem, buf, sched_cap);
+        cx.stage_schedule(cd, c, rows, subs, entries);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wg_barrier();
+        for (; c < n_cells; c += stride) {
+            const int c1 = c + stride, c2 = c + 2 * stride;
+            cx.bind(cd, smem, buf, sched_cap);
+            cx.zero_idle_rows();
+            if (c1 < n_cells) cx.prefetch_schedule(cd1, c1, smem, buf ^ 1, sched_cap, rows, subs, entries);
+            if (cx.nrows != 0) cx.gather(P, Q, 0, cx.nrows);
+            CellDesc cd2 = cd1;
+            if (c2 < n_cells) cd2 = cells[c2];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows and the next schedule have landed
+            wg_barrier();
+            if (cx.nrows != 0) cx.template apply<false>(0.f, 0.f, acc);
+            wg_barrier();  // every wave is done with the rows image and this schedule buffer
+            buf ^= 1;
+            cd = cd1;
+            cd1 = cd2;
+        }
+    }
+    // every lane of a group carries the group's sum: keep one copy, a fixed butterfly over the
+    // wave, then waves in index order
+    double v = cx.lig == 0 ? acc : 0.0;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    double* wsum = reinterpret_cast<double*>(smem + 16);
+    __syncthreads();
+    if (cx.lane == 0) wsum[cx.wave] = v;
+    __syncthreads();
+    if (cx.tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < W; ++w) t += wsum[w];
+        sse_partial[blockIdx.x] = t;
+    }
+}
+
 // Fixed-order reduction of the per-cell partial sums (one workgroup).
 __global__ void __launch_bounds__(256) reduce_sse_kernel(const double* __restrict__ partial,
                                                          const int64_t n, double* __restrict__ out) {
@@ -860,6 +915,27 @@ hipError_t launch_cell(bool train, int L, int W, const CellLaunch& a, hipStream_
     }
 }
 
+template <int L, int W>
+hipError_t sse_LW(const CellLaunch& a, int n_cells, hipStream_t st) {
+    const void* fn = (const void*)sse_kernel<L, W>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((sse_kernel<L, W>), dim3((unsigned)a.grid), dim3(64 * W), (size_t)a.lds_bytes, st, a.P, a.Q, a.cells,
+                       a.rows, a.subs, a.entries, n_cells, a.sse_partial, a.sched_cap);
+    return hipGetLastError();
+}
+
+template <int L>
+hipError_t sse_L(int W, const CellLaunch& a, int n_cells, hipStream_t st) {
+    switch (W) {
+        case 1: return sse_LW<L, 1>(a, n_cells, st);
+        case 2: return sse_LW<L, 2>(a, n_cells, st);
+        case 4: return sse_LW<L, 4>(a, n_cells, st);
+        case 8: return sse_LW<L, 8>(a, n_cells, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t epoch_blocks_per_cu(int L, int W, const CellLaunch& a, int* blocks_per_cu) {
     return epoch_dispatch(0, L, W, a, 0, nullptr, nullptr, blocks_per_cu, nullptr);
 }
@@ -867,6 +943,19 @@ hipError_t epoch_blocks_per_cu(int L, int W, const CellLaunch& a, int* blocks_pe
 hipError_t launch_epoch_persistent(int L, int W, const CellLaunch& a, int n_rounds, unsigned* done,
                                    unsigned* abort_word, hipStream_t st) {
     return epoch_dispatch(1, L, W, a, n_rounds, done, abort_word, nullptr, st);
+}
+
+hipError_t launch_sse_persistent(int L, int W, const CellLaunch& a, int n_cells, hipStream_t st) {
+    switch (L) {
+        case 1: return sse_L<1>(W, a, n_cells, st);
+        case 2: return sse_L<2>(W, a, n_cells, st);
+        case 4: return sse_L<4>(W, a, n_cells, st);
+        case 8: return sse_L<8>(W, a, n_cells, st);
+        case 16: return sse_L<16>(W, a, n_cells, st);
+        case 32: return sse_L<32>(W, a, n_cells, st);
+        case 64: return sse_L<64>(W, a, n_cells, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_reduce_sse(const double* partial, int64_t n, double* out, hipStream_t st) {

@@ -36,6 +36,8 @@ constexpr int kDoneStride = 32;
 hipError_t epoch_blocks_per_cu(int L, int W, const CellLaunch& a, int* blocks_per_cu);
 hipError_t launch_epoch_persistent(int L, int W, const CellLaunch& a, int n_rounds, unsigned* done,
                                    unsigned* abort_word, hipStream_t st);
+// SSE pass, persistent form: a.grid workgroups walk n_cells cells; a.sse_partial gets a.grid doubles.
+hipError_t launch_sse_persistent(int L, int W, const CellLaunch& a, int n_cells, hipStream_t st);
 hipError_t launch_reduce_sse(const double* partial, int64_t n, double* out, hipStream_t st);
 hipError_t launch_predict(int L, const float* P, const float* Q, const int32_t* u, const int32_t* i,
                           float* out, int64_t n, hipStream_t st);
