@@ -86,12 +86,14 @@ typedef struct mfsgd_schedule_info {
     int64_t total_steps;  /* wave steps over all cells                              */
     int64_t total_rows;   /* factor rows gathered (and scattered) per epoch         */
     int64_t max_cell_nnz;
-    int64_t max_cell_rows;
+    int64_t max_cell_rows;  /* rows of the largest chunk */
     int64_t max_cell_steps; /* critical path of the slowest cell (sum over sub-rounds of max wave steps) */
     int64_t sum_round_steps; /* sum over rounds of the slowest cell's critical path */
     double build_seconds;
     int32_t swapped;      /* 1: roles exchanged (users on the kernel's forwarding side): in the   */
     int32_t device_ingest; /* 1: degree histograms and bucket order were computed on the GPU      */
+    int64_t chunks;       /* chunk descriptors (>= blocks*blocks: one per cell + extra chunks)    */
+    int64_t split_cells;  /* cells cut into more than one chunk because they exceed the LDS       */
 } mfsgd_schedule_info;
 
 /* ---- lifetime ------------------------------------------------------------- */
@@ -179,7 +181,9 @@ int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t
 
 /* Diagnostic (not part of the Java surface): the device-facing schedule arrays of a
  * partition, so that tests can replay the kernel's exact LDS access order on the CPU.
- * cells: n_cells x 4 words {row_off, ent_off, n_steps, nu | ni << 16};
+ * cells: n_cells x 8 words {row_off, ent_off, n_steps, nu | ni << 16, next chunk, 3 reserved}: chunk
+ * descriptors -- the first blocks*blocks are the first chunk of each cell, a cell too large for
+ * the LDS continues through `next` (0 = last chunk) into the descriptors behind them;
  * subs: n_subs x 2 words {off, general steps | run steps << 16};
  * entries: n_entries x 4 words {p addr | q addr << 16 | flag << 31 (16-byte units), rating bits,
  * bits of lr*rating, bits of the slot's decay factor}.                                         */

@@ -47,6 +47,8 @@ class ScheduleInfo(C.Structure):
         ("build_seconds", C.c_double),
         ("swapped", C.c_int32),
         ("device_ingest", C.c_int32),
+        ("chunks", C.c_int64),
+        ("split_cells", C.c_int64),
     ]
 
     def as_dict(self):

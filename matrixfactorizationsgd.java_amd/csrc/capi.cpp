@@ -163,7 +163,7 @@ int ensure_part_on_device(mfsgd_handle* h, Part& p) {
     if ((rc = upload(h, p.d_rows, p.sched.rows))) return rc;
     if ((rc = upload(h, p.d_subs, p.sched.subs))) return rc;
     if ((rc = upload(h, p.d_entries, p.sched.entries))) return rc;
-    if ((rc = dev_alloc(h, p.d_sse_partial, sizeof(double) * (size_t)p.sched.B * p.sched.B))) return rc;
+    if ((rc = dev_alloc(h, p.d_sse_partial, sizeof(double) * p.sched.cells.size()))) return rc;
     if ((rc = dev_alloc(h, p.d_sse_out, sizeof(double)))) return rc;
     if ((rc = dev_alloc(h, p.d_sync, sync_bytes(p)))) return rc;
     HIPCHK(h, hipMemset(p.d_sync.p, 0, sync_bytes(p)));
@@ -287,8 +287,8 @@ int check_abort(mfsgd_handle* h, Part& p) {
 
 int launch_sse(mfsgd_handle* h, Part& p, const float* Q, hipStream_t st) {
     CellLaunch a = make_launch(h, p, const_cast<float*>(Q));
-    const int n_cells = p.sched.B * p.sched.B;
-    if (h->cfg.flags & MFSGD_FLAG_ROUND_LAUNCH) {  // reference form: one workgroup per cell
+    const int n_cells = (int)p.sched.cells.size();  // chunk descriptors: every one is independent here
+    if (h->cfg.flags & MFSGD_FLAG_ROUND_LAUNCH) {  // reference form: one workgroup per chunk
         a.grid = n_cells;
         HIPCHK(h, launch_cell(false, h->geo.L, p.sched.W, a, st));
     } else {
@@ -792,6 +792,8 @@ int mfsgd_get_schedule_info(const mfsgd_handle* h, int32_t part, mfsgd_schedule_
     out->build_seconds = s.build_seconds;
     out->swapped = h->parts[(size_t)part].swapped ? 1 : 0;
     out->device_ingest = s.device_ingest ? 1 : 0;
+    out->chunks = (int64_t)s.cells.size();
+    out->split_cells = s.split_cells;
     return MFSGD_OK;
 }
 
@@ -840,7 +842,7 @@ int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgro
     if ((rc = probe_persistent(h, p))) return rc;
     if (p.persistent_np <= 0) return fail(h, MFSGD_ERR_STATE, "debug_epoch_profile: persistent kernel not in use");
     const size_t words = (size_t)p.persistent_np * 8;
-    if ((rc = dev_alloc(h, p.d_sse_partial, std::max(words * sizeof(uint64_t), sizeof(double) * (size_t)p.sched.B * p.sched.B)))) return rc;
+    if ((rc = dev_alloc(h, p.d_sse_partial, std::max(words * sizeof(uint64_t), sizeof(double) * p.sched.cells.size())))) return rc;
     CellLaunch a = make_launch(h, p, static_cast<float*>(h->dQ.p));
     a.grid = p.persistent_np;
     a.diag = true;

@@ -206,7 +206,7 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
 //
 // LDS image of a workgroup:
 //   [control block 16 B][schedule buffer 0: sched_cap][schedule buffer 1: sched_cap][rows ...]
-//   schedule buffer: [entries: n_steps x G x 16][subs: W*W x 8][row ids: nrows x 4]
+//   schedule buffer: [entries: n_steps x G x 16][subs: W*W x 8, padded to 16][row ids: nrows x 4]
 //   rows: [nrows x ROWB][2G zero rows]; slots [0, nu) hold p-side (user) rows, [nu, nrows) q-side (item) rows.
 // Two schedule buffers: the persistent kernel fetches the next cell's schedule (LDS-DMA)
 // while the current cell is being worked on.
@@ -217,6 +217,7 @@ struct Cell {
     static constexpr int KP = 4 * L;
     static constexpr int NT = 64 * W;
     static constexpr int CTL = 16;  // control block at the start of the dynamic LDS
+    static constexpr int SUBB = (W * W * 8 + 15) & ~15;  // sub-cell table, padded to 16-byte units
 
     int tid, lane, wave, g, lig;
     unsigned laneoff;
@@ -243,7 +244,7 @@ struct Cell {
         lrows = smem + CTL + 2 * (size_t)sched_cap;
         lent = reinterpret_cast<uint4*>(smem + CTL + (size_t)buf * sched_cap);
         lsub = reinterpret_cast<uint2*>(lent + (size_t)n_steps * G);
-        lids = reinterpret_cast<uint32_t*>(lsub + W * W);
+        lids = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(lsub) + SUBB);
     }
 
     // Zeroes the 2G rows idle step slots point at (r = 0 keeps them zero).
@@ -262,7 +263,7 @@ struct Cell {
         unsigned char* const dst = smem + CTL + (size_t)buf * sched_cap;
         const int nn = (int)nd.nu + (int)nd.ni;
         const int ent_bytes = (int)(nd.n_steps & 0x7FFFFFFFu) * G * 16;
-        const int sub_bytes = W * W * 8;
+        const int sub_bytes = SUBB;
         const int ids_bytes = (nn * 4 + 15) & ~15;
         auto copy = [&](const unsigned char* src, unsigned char* d, int bytes) {
             for (int off0 = wave * 1024; off0 < bytes; off0 += W * 1024) {
@@ -505,7 +506,8 @@ struct Cell {
 };
 
 // One workgroup = one cell, one launch = one round.  TRAIN: round `rd` runs cells
-// (b, (b + rd) % B).  !TRAIN: blockIdx.x is the cell index, no writes, SSE out.
+// (b, (b + rd) % B), each workgroup walking the chunks of its cell.  !TRAIN: blockIdx.x
+// is a chunk descriptor index (every chunk on its own), no writes, SSE out.
 template <int L, int W, bool TRAIN, bool DIAG = false>
 __global__ void __launch_bounds__(64 * W)
 cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __restrict__ cells,
@@ -515,37 +517,40 @@ cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Cell<L, W> cx;
     cx.init_thread();
-    const int cell = TRAIN ? (int)blockIdx.x * B + ((int)blockIdx.x + rd) % B : (int)blockIdx.x;
-    const CellDesc cd = cells[cell];
+    int cell = TRAIN ? (int)blockIdx.x * B + ((int)blockIdx.x + rd) % B : (int)blockIdx.x;
     unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0, real0 = 0;
     if constexpr (DIAG) {
         stamp0 = __builtin_amdgcn_s_memtime();
         real0 = __builtin_amdgcn_s_memrealtime();
     }
-    cx.bind(cd, smem, 0, sched_cap);
-    if (cx.nrows == 0) {  // uniform over the workgroup
-        if (!TRAIN && cx.tid == 0) sse_partial[cell] = 0.0;
-        return;
-    }
-    cx.stage_schedule(cd, cell, rows, subs, entries);
-    __syncthreads();
-    cx.gather(P, Q, 0, cx.nrows);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if constexpr (DIAG) stamp1 = __builtin_amdgcn_s_memtime();
-
     double acc = 0.0;
-    if constexpr (DIAG)
-        cx.template apply<TRAIN, true>(lr, c, acc, reinterpret_cast<unsigned long long*>(sse_partial) +
-                                                       (size_t)gridDim.x * 6 + (size_t)blockIdx.x * W * W * 4);
-    else
-        cx.template apply<TRAIN>(lr, c, acc);
-
-    if constexpr (DIAG) stamp2 = __builtin_amdgcn_s_memtime();
-    if constexpr (TRAIN) {
+    for (;;) {
+        const CellDesc cd = cells[cell];
+        cx.bind(cd, smem, 0, sched_cap);
+        if (cx.nrows == 0) break;  // uniform over the workgroup; an empty cell has no further chunk
+        cx.stage_schedule(cd, cell, rows, subs, entries);
+        __syncthreads();
+        cx.gather(P, Q, 0, cx.nrows);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (DIAG) stamp1 = __builtin_amdgcn_s_memtime();
+        if constexpr (DIAG)
+            cx.template apply<TRAIN, true>(lr, c, acc, reinterpret_cast<unsigned long long*>(sse_partial) +
+                                                           (size_t)gridDim.x * 6 + (size_t)blockIdx.x * W * W * 4);
+        else
+            cx.template apply<TRAIN>(lr, c, acc);
+        if constexpr (DIAG) stamp2 = __builtin_amdgcn_s_memtime();
+        if constexpr (!TRAIN) break;
         cx.template scatter<false>(P, Q, 0, cx.nrows);
+        if (cd.next == 0) break;
+        // next chunk of this cell: its gathers may read rows stored just now, and it reuses the LDS image
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cell = (int)cd.next;
+    }
+    if constexpr (TRAIN) {
         if constexpr (DIAG) {
-            // diagnostic build only: phase stamps of this workgroup
+            // diagnostic build only: phase stamps of this workgroup (of the last chunk it ran)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
             const unsigned long long real3 = __builtin_amdgcn_s_memrealtime();
@@ -566,14 +571,14 @@ cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __rest
         double v = cx.lig == 0 ? acc : 0.0;
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-        __syncthreads();  // everyone is done reading lsub/lent before they are reused
-        double* wsum = reinterpret_cast<double*>(cx.lent);
+        __syncthreads();  // everyone is done reading the schedule buffer before it is reused
+        double* wsum = reinterpret_cast<double*>(smem + 16);
         if (cx.lane == 0) wsum[cx.wave] = v;
         __syncthreads();
         if (cx.tid == 0) {
             double t = 0.0;
             for (int w = 0; w < W; ++w) t += wsum[w];
-            sse_partial[cell] = t;
+            sse_partial[blockIdx.x] = t;
         }
     }
 }
@@ -610,27 +615,39 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     cx.init_thread();
     if (cx.tid == 0) ctl[0] = 0;
 
-    // This workgroup's work list: (round R, block b) for b = blockIdx.x, +NP, ... in round order.
-    auto cell_of = [&](int R, int b) { return b * B + (b + R % B) % B; };
-    auto advance = [&](int& R, int& b) {
-        b += NP;
-        if (b >= B) {
-            b = wg;
-            ++R;
+    // This workgroup's work list: (round R, block b) for b = blockIdx.x, +NP, ... in round order,
+    // and within a cell its chunks in chain order.
+    struct Item {
+        int R, b;
+        unsigned idx;  // chunk descriptor
+        bool first;    // first chunk of its cell: the tile has to be waited for
+    };
+    auto cell_of = [&](int R, int b) { return (unsigned)(b * B + (b + R % B) % B); };
+    auto next_item = [&](const Item& it, const CellDesc& d) {
+        Item n = it;
+        if (d.next != 0) {
+            n.idx = d.next;
+            n.first = false;
+        } else {
+            n.b += NP;
+            if (n.b >= B) {
+                n.b = wg;
+                ++n.R;
+            }
+            n.idx = cell_of(n.R, n.b);
+            n.first = true;
         }
+        return n;
     };
     // Software pipeline over the list: descriptors are fetched two items ahead (registers),
     // schedules one item ahead (LDS-DMA into the other schedule buffer).
-    int R = 0, b = wg;
-    int R1 = R, b1 = b;
-    advance(R1, b1);
-    int R2 = R1, b2 = b1;
-    advance(R2, b2);
-    CellDesc cd = cells[cell_of(R, b)];
-    CellDesc cd1 = R1 < n_rounds ? cells[cell_of(R1, b1)] : cd;
+    Item it0{0, wg, cell_of(0, wg), true};
+    CellDesc cd = cells[it0.idx];
+    Item it1 = next_item(it0, cd);
+    CellDesc cd1 = it1.R < n_rounds ? cells[it1.idx] : cd;
     int buf = 0;
     cx.bind(cd, smem, buf, sched_cap);
-    cx.stage_schedule(cd, cell_of(R, b), rows, subs, entries);  // the first one synchronously
+    cx.stage_schedule(cd, (int)it0.idx, rows, subs, entries);  // the first one synchronously
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();
 
@@ -646,17 +663,19 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     };
     if (prof) pt = __builtin_amdgcn_s_memtime();
 
-    for (; R < n_rounds;) {
+    for (; it0.R < n_rounds;) {
+        const int R = it0.R, b = it0.b;
         CellDesc cd2 = cd1;
         cx.bind(cd, smem, buf, sched_cap);
         const bool work = cx.nrows != 0;  // uniform over the workgroup
+        const bool last = cd.next == 0;   // last chunk of its cell: the tile is handed on after it
         cx.zero_idle_rows();
-        // The P rows stored at the end of the previous iteration may be gathered again below.
+        // The rows stored at the end of the previous iteration may be gathered again below.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (R1 < n_rounds) cx.prefetch_schedule(cd1, cell_of(R1, b1), smem, buf ^ 1, sched_cap, rows, subs, entries);
+        if (it1.R < n_rounds) cx.prefetch_schedule(cd1, (int)it1.idx, smem, buf ^ 1, sched_cap, rows, subs, entries);
         if (work) cx.gather(P, Q, 0, cx.nu);  // own rows: no dependency on other workgroups
-        mark(0);  // drain of the previous P stores + issue of the prefetch and the P gather
-        if (R > 0) {
+        mark(0);  // drain of the previous stores + issue of the prefetch and the P gather
+        if (R > 0 && it0.first) {
             // wait until block b + 1 has finished round R - 1 (it held our tile)
             if (cx.tid == 0) {
                 gu32* flag = (gu32*)(done + (size_t)((b + 1) % B) * kFlagStride);
@@ -676,13 +695,14 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
-        mark(1);  // waiting for the tile (wave 0) 
+        mark(1);  // waiting for the tile (wave 0)
         wg_barrier();
         mark(2);  // the other waves' arrival
         if (ctl[0] != 0) return;  // uniform: some workgroup timed out
         // descriptor used two iterations from now: issued here so that no wait of this
         // iteration's latency-critical part (the drain above, the tile poll) sits behind it
-        if (R2 < n_rounds) cd2 = cells[cell_of(R2, b2)];
+        const Item it2 = next_item(it1, cd1);
+        if (it2.R < n_rounds) cd2 = cells[it2.idx];
         if (work) {
             cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows (and the prefetched schedule) have landed
@@ -691,12 +711,14 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
             double acc = 0.0;
             cx.template apply<true>(lr, c, acc);  // ends with a workgroup barrier
             mark(4);  // the ratings
+            // write-through even when more chunks of this cell follow: item rows that no later
+            // chunk touches have to be visible to the next workgroup all the same
             cx.template scatter<true>(P, Q, cx.nu, cx.nrows);
         }
         // publish the tile: every storing wave drains, then one lane signals
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wg_barrier();
-        if (cx.tid == 0)
+        if (last && cx.tid == 0)
             __hip_atomic_store((gu32*)(done + (size_t)b * kFlagStride), (unsigned)(R + 1), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         mark(5);  // tile rows stored write-through, drained, flag published
@@ -708,11 +730,8 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         buf ^= 1;
         cd = cd1;
         cd1 = cd2;
-        R = R1;
-        b = b1;
-        R1 = R2;
-        b1 = b2;
-        advance(R2, b2);
+        it0 = it1;
+        it1 = it2;
         mark(6);  // own rows stored (not drained), end barrier
     }
     if (prof && cx.tid == 0)

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <iterator>
 #include <numeric>
 #include <queue>
 #include <thread>
@@ -27,8 +29,8 @@ Geometry geometry_for_k(int k) {
 }
 
 int64_t sched_bytes_for(const Geometry& geo, int W, int nrows, int64_t n_steps) {
-    const int64_t b = n_steps * geo.G * 16 + (int64_t)W * W * 8 + (int64_t)nrows * 4;
-    return (b + 15) & ~(int64_t)15;
+    // three sections, each a whole number of 16-byte units (the staging DMA copies such units)
+    return n_steps * geo.G * 16 + (((int64_t)W * W * 8 + 15) & ~(int64_t)15) + (((int64_t)nrows * 4 + 15) & ~(int64_t)15);
 }
 
 int64_t rows_bytes_for(const Geometry& geo, int nrows) { return (int64_t)(nrows + 2 * geo.G) * geo.rowbytes; }
@@ -63,6 +65,13 @@ struct Rat {
     uint16_t p, q;  // LDS slots
     float r;
     int64_t idx;    // caller-visible rating index
+};
+
+struct RawRat {
+    uint32_t u, i;
+    float r;
+    int64_t idx;
+    uint16_t sb;  // sub-cell inside the cell: sub-round * W + wave
 };
 
 struct CellOut {
@@ -384,177 +393,396 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
 
     // ---- per-cell packing (parallel over cells) ------------------------------
     const int64_t ncell = (int64_t)B * B;
-    std::vector<CellOut> co((size_t)ncell);
-    std::atomic<int64_t> next_cell{0};
-    std::atomic<int> failed{0};
-    std::string fail_msg;
     const int WW = W * W;
     const Hyper hy{prm.lr, 1.0f - prm.lr * prm.lambda};
-    auto worker = [&]() {
-        Scratch sc;
-        for (;;) {
-            const int64_t c = next_cell.fetch_add(1);
-            if (c >= ncell || failed.load()) break;
-            const int64_t lo = bptr[(size_t)(c * WW)], hi = bptr[(size_t)((c + 1) * WW)];
-            CellOut& o = co[(size_t)c];
-            o.subs.assign((size_t)WW, SubDesc{0, 0});
-            if (hi == lo) continue;
-            const int64_t m = hi - lo;
-            sc.us.resize((size_t)m);
-            sc.is.resize((size_t)m);
+    const int64_t avail = (int64_t)prm.lds_budget - 16;
+    const int64_t min_sched = sched_bytes_for(geo, W, 2, 3), min_rows = rows_bytes_for(geo, 2);
+    if (avail < 2 * min_sched + min_rows) {
+        err = "lds: the LDS budget cannot hold a single rating at this k";
+        return -1;
+    }
+    std::atomic<int> failed{0};
+    std::string fail_msg;
+
+    // One chunk: the ratings `sel` (bucket order, so sub-cells are contiguous) packed as a complete
+    // little cell.  Returns false when a sub-cell overflows the 16-bit step counts (caller splits).
+    auto pack_chunk = [&](const std::vector<RawRat>& sel, CellOut& o, Scratch& sc) -> bool {
+        const int64_t m = (int64_t)sel.size();
+        o = CellOut{};
+        o.subs.assign((size_t)WW, SubDesc{0, 0});
+        std::vector<uint32_t>& uu = sc.us;
+        std::vector<uint32_t>& ii = sc.is;
+        uu.resize((size_t)m);
+        ii.resize((size_t)m);
+        for (int64_t x = 0; x < m; ++x) {
+            uu[(size_t)x] = sel[(size_t)x].u;
+            ii[(size_t)x] = sel[(size_t)x].i;
+        }
+        std::sort(uu.begin(), uu.end());
+        uu.erase(std::unique(uu.begin(), uu.end()), uu.end());
+        std::sort(ii.begin(), ii.end());
+        ii.erase(std::unique(ii.begin(), ii.end()), ii.end());
+        const int nu = (int)uu.size(), ni = (int)ii.size(), nrows = nu + ni;
+        o.nu = (uint32_t)nu;
+        o.ni = (uint32_t)ni;
+        o.rows.reserve((size_t)nrows);
+        o.rows.insert(o.rows.end(), uu.begin(), uu.end());
+        o.rows.insert(o.rows.end(), ii.begin(), ii.end());
+        sc.rats.resize((size_t)m);
+        int64_t sub_lo[65];  // first rating of sub-cell x (x = s * W + w), sub_lo[WW] = m
+        {
+            int nxt = 0;
             for (int64_t x = 0; x < m; ++x) {
-                const int64_t j = sorted[(size_t)(lo + x)];
-                sc.us[(size_t)x] = (uint32_t)u[j];
-                sc.is[(size_t)x] = (uint32_t)i[j];
-            }
-            std::vector<uint32_t> uu(sc.us.begin(), sc.us.begin() + m), ii(sc.is.begin(), sc.is.begin() + m);
-            std::sort(uu.begin(), uu.end());
-            uu.erase(std::unique(uu.begin(), uu.end()), uu.end());
-            std::sort(ii.begin(), ii.end());
-            ii.erase(std::unique(ii.begin(), ii.end()), ii.end());
-            const int nu = (int)uu.size(), ni = (int)ii.size(), nrows = nu + ni;
-            if ((int64_t)(nrows + 2 * G) * geo.L > 32767) {
-                if (!failed.exchange(1)) fail_msg = "lds: cell touches more rows than LDS can address";
-                break;
-            }
-            o.nu = (uint32_t)nu;
-            o.ni = (uint32_t)ni;
-            o.rows.reserve((size_t)nrows);
-            o.rows.insert(o.rows.end(), uu.begin(), uu.end());
-            o.rows.insert(o.rows.end(), ii.begin(), ii.end());
-            sc.rats.resize((size_t)m);
-            for (int64_t x = 0; x < m; ++x) {
-                const int64_t j = sorted[(size_t)(lo + x)];
+                const RawRat& a = sel[(size_t)x];
+                while (nxt <= (int)a.sb) sub_lo[nxt++] = x;
                 Rat t;
-                t.p = (uint16_t)(std::lower_bound(uu.begin(), uu.end(), (uint32_t)u[j]) - uu.begin());
-                t.q = (uint16_t)(nu + (std::lower_bound(ii.begin(), ii.end(), (uint32_t)i[j]) - ii.begin()));
-                t.r = r[j];
-                t.idx = orig ? orig[j] : j;
+                t.p = (uint16_t)(std::lower_bound(uu.begin(), uu.end(), a.u) - uu.begin());
+                t.q = (uint16_t)(nu + (std::lower_bound(ii.begin(), ii.end(), a.i) - ii.begin()));
+                t.r = a.r;
+                t.idx = a.idx;
                 sc.rats[(size_t)x] = t;
             }
-            sc.remdeg.assign((size_t)nrows, 0);
-            sc.laststep.assign((size_t)nrows, 0);
-            sc.lastslot.assign((size_t)nrows, (int8_t)-1);
-            sc.prevstep.assign((size_t)nrows, 0);
-            int32_t tstamp = 1;               // step stamps start at 2 so that t-1 never matches 0
-            o.entries.reserve((size_t)(m + m / 2 + G));
-            o.order.reserve((size_t)m);
-            uint32_t stepcur = 0;
-            int64_t crit = 0;
-            for (int s = 0; s < W; ++s) {
-                uint32_t smax = 0;
-                for (int w = 0; w < W; ++w) {
-                    const int64_t sb = c * WW + (int64_t)s * W + w;
-                    const int64_t slo = bptr[(size_t)sb] - lo, shi = bptr[(size_t)sb + 1] - lo;
-                    uint32_t ns = 0, nr = 0;
-                    const int nsub = (int)(shi - slo);
-                    Rat* sub = sc.rats.data() + slo;
-                    // run items: the (at most G) items whose ratings would dominate the step
-                    // count of this sub-cell; their ratings go last, in run mode
-                    uint16_t run_q[64];
-                    int nrun = 0;
-                    if (nsub >= kRunMin) {
-                        for (int j = 0; j < nsub; ++j) sc.remdeg[sub[j].q]++;
-                        std::vector<std::pair<int32_t, uint16_t>>& top = sc.top;
-                        top.clear();
-                        for (int j = 0; j < nsub; ++j) {
-                            const int32_t d = sc.remdeg[sub[j].q];
-                            if (d >= kRunMin && d * G >= nsub) top.push_back({-d, sub[j].q});
-                        }
-                        for (int j = 0; j < nsub; ++j) sc.remdeg[sub[j].q] = 0;
-                        std::sort(top.begin(), top.end());
-                        top.erase(std::unique(top.begin(), top.end()), top.end());
-                        for (size_t x = 0; x < top.size() && nrun < G; ++x) run_q[nrun++] = top[x].second;
+            while (nxt <= WW) sub_lo[nxt++] = m;
+        }
+        sc.remdeg.assign((size_t)nrows, 0);
+        sc.laststep.assign((size_t)nrows, 0);
+        sc.lastslot.assign((size_t)nrows, (int8_t)-1);
+        sc.prevstep.assign((size_t)nrows, 0);
+        int32_t tstamp = 1;  // step stamps start at 2 so that t-1 never matches 0
+        o.entries.reserve((size_t)(m + m / 2 + G));
+        o.order.reserve((size_t)m);
+        uint32_t stepcur = 0;
+        int64_t crit = 0;
+        for (int s = 0; s < W; ++s) {
+            uint32_t smax = 0;
+            for (int w = 0; w < W; ++w) {
+                const int64_t slo = sub_lo[s * W + w], shi = sub_lo[s * W + w + 1];
+                uint32_t ns = 0, nr = 0;
+                const int nsub = (int)(shi - slo);
+                Rat* sub = sc.rats.data() + slo;
+                // run items: the (at most G) items whose ratings would dominate the step
+                // count of this sub-cell; their ratings go last, in run mode
+                uint16_t run_q[64];
+                int nrun = 0;
+                if (nsub >= kRunMin) {
+                    for (int j = 0; j < nsub; ++j) sc.remdeg[sub[j].q]++;
+                    std::vector<std::pair<int32_t, uint16_t>>& top = sc.top;
+                    top.clear();
+                    for (int j = 0; j < nsub; ++j) {
+                        const int32_t d = sc.remdeg[sub[j].q];
+                        if (d >= kRunMin && d * G >= nsub) top.push_back({-d, sub[j].q});
                     }
-                    int ngen = nsub;
-                    if (nrun > 0) {
-                        // stable partition: general ratings first, run ratings after
-                        auto is_run = [&](const Rat& x) {
-                            for (int g = 0; g < nrun; ++g)
-                                if (run_q[g] == x.q) return true;
-                            return false;
-                        };
-                        ngen = (int)(std::stable_partition(sub, sub + nsub, [&](const Rat& x) { return !is_run(x); }) - sub);
-                    }
-                    ++tstamp;  // break stickiness across sub-cells
-                    pack_subcell(sub, ngen, G, geo.L, nrows, hy, sc, tstamp, o.entries, o.order, ns);
-                    if (nrun > 0) {
-                        ++tstamp;  // the run starts with fresh loads: no hazard against the last general step
-                        pack_run(sub + ngen, nsub - ngen, run_q, nrun, G, geo.L, nrows, hy, sc, tstamp, o.entries,
-                                 o.order, nr);
-                    }
-                    if (ns > 0xFFFF || nr > 0xFFFF) {
-                        if (!failed.exchange(1)) fail_msg = "lds: sub-cell has more than 65535 steps";
-                        break;
-                    }
-                    if (nr > 0) o.has_run = true;
-                    o.subs[(size_t)(s * W + w)] = SubDesc{stepcur, ns | (nr << 16)};
-                    stepcur += ns + nr;
-                    smax = std::max(smax, ns + nr);
+                    for (int j = 0; j < nsub; ++j) sc.remdeg[sub[j].q] = 0;
+                    std::sort(top.begin(), top.end());
+                    top.erase(std::unique(top.begin(), top.end()), top.end());
+                    for (size_t x = 0; x < top.size() && nrun < G; ++x) run_q[nrun++] = top[x].second;
                 }
-                crit += smax;
+                int ngen = nsub;
+                if (nrun > 0) {
+                    // stable partition: general ratings first, run ratings after
+                    auto is_run = [&](const Rat& x) {
+                        for (int g = 0; g < nrun; ++g)
+                            if (run_q[g] == x.q) return true;
+                        return false;
+                    };
+                    ngen = (int)(std::stable_partition(sub, sub + nsub, [&](const Rat& x) { return !is_run(x); }) - sub);
+                }
+                ++tstamp;  // break stickiness across sub-cells
+                pack_subcell(sub, ngen, G, geo.L, nrows, hy, sc, tstamp, o.entries, o.order, ns);
+                if (nrun > 0) {
+                    ++tstamp;  // the run starts with fresh loads: no hazard against the last general step
+                    pack_run(sub + ngen, nsub - ngen, run_q, nrun, G, geo.L, nrows, hy, sc, tstamp, o.entries, o.order,
+                             nr);
+                }
+                if (ns > 0xFFFF || nr > 0xFFFF) return false;
+                if (nr > 0) o.has_run = true;
+                o.subs[(size_t)(s * W + w)] = SubDesc{stepcur, ns | (nr << 16)};
+                stepcur += ns + nr;
+                smax = std::max(smax, ns + nr);
             }
-            // two trailing idle steps: the kernel reads entries t+1 and t+2 ahead
-            for (int pad = 0; pad < 2; ++pad)
-                for (int g = 0; g < G; ++g)
-                    o.entries.push_back(make_entry(encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, geo.L), 0.0f, hy.c, hy));
-            o.n_steps = stepcur + 2;
-            o.crit = crit;
+            crit += smax;
+        }
+        // two trailing idle steps: the kernel reads entries t+1 and t+2 ahead
+        for (int pad = 0; pad < 2; ++pad)
+            for (int g = 0; g < G; ++g)
+                o.entries.push_back(make_entry(encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, geo.L), 0.0f, hy.c, hy));
+        o.n_steps = stepcur + 2;
+        o.crit = crit;
+        return true;
+    };
+    auto load_cell = [&](int64_t c, std::vector<RawRat>& sel) {
+        const int64_t lo = bptr[(size_t)(c * WW)], hi = bptr[(size_t)((c + 1) * WW)];
+        sel.resize((size_t)(hi - lo));
+        int sb = 0;
+        for (int64_t x = lo; x < hi; ++x) {
+            while (bptr[(size_t)(c * WW + sb + 1)] <= x) ++sb;
+            const int64_t j = sorted[(size_t)x];
+            sel[(size_t)(x - lo)] = RawRat{(uint32_t)u[j], (uint32_t)i[j], r[j], orig ? orig[j] : j, (uint16_t)sb};
         }
     };
-    {
+    auto distinct_rows = [&](const std::vector<RawRat>& sel, Scratch& sc, int& nu, int& ni) {
+        sc.us.resize(sel.size());
+        sc.is.resize(sel.size());
+        for (size_t x = 0; x < sel.size(); ++x) {
+            sc.us[x] = sel[x].u;
+            sc.is[x] = sel[x].i;
+        }
+        std::sort(sc.us.begin(), sc.us.end());
+        std::sort(sc.is.begin(), sc.is.end());
+        nu = (int)(std::unique(sc.us.begin(), sc.us.end()) - sc.us.begin());
+        ni = (int)(std::unique(sc.is.begin(), sc.is.end()) - sc.is.begin());
+    };
+    auto addressable = [&](int nrows) { return (int64_t)(nrows + 2 * G) * geo.L <= 32767; };
+    auto run_parallel = [&](const std::function<void(Scratch&, std::vector<RawRat>&)>& body) {
         std::vector<std::thread> th;
+        auto w = [&]() {
+            Scratch sc;
+            std::vector<RawRat> sel;
+            body(sc, sel);
+        };
         const int nt = (int)std::min<int64_t>(nthreads, ncell);
-        for (int t = 1; t < nt; ++t) th.emplace_back(worker);
-        worker();
+        for (int t = 1; t < nt; ++t) th.emplace_back(w);
+        w();
         for (auto& t : th) t.join();
+    };
+
+    // Phase 1: every cell as a single chunk, unless it cannot possibly fit.
+    std::vector<CellOut> co((size_t)ncell);
+    std::vector<uint8_t> oversize((size_t)ncell, 0);
+    {
+        std::atomic<int64_t> next_cell{0};
+        run_parallel([&](Scratch& sc, std::vector<RawRat>& sel) {
+            for (;;) {
+                const int64_t c = next_cell.fetch_add(1);
+                if (c >= ncell) break;
+                CellOut& o = co[(size_t)c];
+                if (bptr[(size_t)(c * WW)] == bptr[(size_t)((c + 1) * WW)]) {
+                    o.subs.assign((size_t)WW, SubDesc{0, 0});
+                    continue;
+                }
+                load_cell(c, sel);
+                int nu, ni;
+                distinct_rows(sel, sc, nu, ni);
+                if (!addressable(nu + ni) || rows_bytes_for(geo, nu + ni) + 2 * min_sched > avail ||
+                    !pack_chunk(sel, o, sc)) {
+                    o = CellOut{};
+                    o.nu = (uint32_t)nu;  // kept for the limit search below
+                    o.ni = (uint32_t)ni;
+                    o.order.resize(sel.size());
+                    oversize[(size_t)c] = 1;
+                }
+            }
+        });
+    }
+    lap("per-cell packing");
+
+    // Limits of one chunk: S bytes of schedule, R bytes of rows, 16 + 2 S + R <= budget.  Chosen to
+    // cut as few cells as possible; when every cell fits as it is nothing is cut (and the caps below
+    // are the actual maxima, not these limits).
+    int64_t lim_s = 0, lim_r = 0;
+    {
+        int64_t max_s = min_sched, max_r = min_rows;
+        bool any_over = false;
+        for (int64_t c = 0; c < ncell; ++c) {
+            const CellOut& o = co[(size_t)c];
+            if (oversize[(size_t)c]) {
+                any_over = true;
+                continue;
+            }
+            if (o.n_steps == 0) continue;
+            max_s = std::max(max_s, sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps));
+            max_r = std::max(max_r, rows_bytes_for(geo, (int)(o.nu + o.ni)));
+        }
+        if (!any_over && 2 * max_s + max_r <= avail) {
+            lim_s = max_s;
+            lim_r = max_r;
+        } else {
+            const int64_t s_hi = std::min(max_s, (avail - min_rows) / 2);
+            constexpr int kCand = 48;
+            double best_cost = -1;
+            for (int x = 0; x <= kCand; ++x) {
+                int64_t S = min_sched + (s_hi - min_sched) * x / kCand;
+                S = (S + 15) & ~(int64_t)15;
+                if (S > (avail - min_rows) / 2) S = ((avail - min_rows) / 2) & ~(int64_t)15;
+                const int64_t R = (avail - 2 * S) & ~(int64_t)15;
+                double cost = 0;
+                for (int64_t c = 0; c < ncell; ++c) {
+                    const CellOut& o = co[(size_t)c];
+                    if (o.nu + o.ni == 0) continue;
+                    const int64_t rb = rows_bytes_for(geo, (int)(o.nu + o.ni));
+                    // an unpacked (oversize) cell: guess its steps from its rating count
+                    const int64_t sb = oversize[(size_t)c]
+                                           ? sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.order.size() * 2 / G + 2)
+                                           : sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps);
+                    if (sb <= S && rb <= R && !oversize[(size_t)c]) continue;
+                    cost += std::max(1.0, std::max((double)sb / (double)S, (double)rb / (double)R));
+                }
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    lim_s = S;
+                    lim_r = R;
+                }
+            }
+        }
+    }
+    lap("  chunk limits");
+
+    // Phase 2: cells over the limits are cut in two (by users or by items, whichever there are more
+    // of; halves balanced by rating count) until every piece fits.
+    std::vector<std::vector<CellOut>> extra((size_t)ncell);
+    {
+        std::vector<int64_t> todo;
+        for (int64_t c = 0; c < ncell; ++c) {
+            const CellOut& o = co[(size_t)c];
+            if (oversize[(size_t)c] ||
+                (o.n_steps != 0 && (sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps) > lim_s ||
+                                    rows_bytes_for(geo, (int)(o.nu + o.ni)) > lim_r)))
+                todo.push_back(c);
+        }
+        std::atomic<int64_t> next_todo{0};
+        run_parallel([&](Scratch& sc, std::vector<RawRat>& sel) {
+            std::vector<CellOut> pieces;
+            std::function<void(std::vector<RawRat>&)> cut = [&](std::vector<RawRat>& part) {
+                if (failed.load()) return;
+                int nu, ni;
+                distinct_rows(part, sc, nu, ni);
+                const int nrows = nu + ni;
+                if (addressable(nrows) && rows_bytes_for(geo, nrows) <= lim_r) {
+                    CellOut o;
+                    if (pack_chunk(part, o, sc) &&
+                        sched_bytes_for(geo, W, nrows, (int64_t)o.n_steps) <= lim_s) {
+                        pieces.push_back(std::move(o));
+                        return;
+                    }
+                }
+                if (part.size() <= 1) {
+                    if (!failed.exchange(1)) fail_msg = "lds: a single rating does not fit the chunk limits";
+                    return;
+                }
+                // (distinct_rows left the sorted distinct ids in sc.us / sc.is; pack_chunk may have
+                // overwritten them, so recompute)
+                distinct_rows(part, sc, nu, ni);
+                if (nu <= 1 && ni <= 1) {
+                    // the same (user, item) pair many times over: any cut of the sequence will do
+                    std::vector<RawRat> left(part.begin(), part.begin() + (long)(part.size() / 2));
+                    std::vector<RawRat> right(part.begin() + (long)(part.size() / 2), part.end());
+                    std::vector<RawRat>().swap(part);
+                    cut(left);
+                    cut(right);
+                    return;
+                }
+                const bool by_user = (nu >= ni && nu > 1) || ni <= 1;
+                const std::vector<uint32_t>& ids = by_user ? sc.us : sc.is;
+                const int nid = by_user ? nu : ni;
+                std::vector<int64_t> cnt((size_t)nid, 0);
+                for (const RawRat& a : part) {
+                    const uint32_t key = by_user ? a.u : a.i;
+                    cnt[(size_t)(std::lower_bound(ids.begin(), ids.begin() + nid, key) - ids.begin())]++;
+                }
+                int64_t half = (int64_t)part.size() / 2, acc = 0;
+                int cutpos = 1;
+                for (int x = 0; x < nid - 1; ++x) {
+                    acc += cnt[(size_t)x];
+                    cutpos = x + 1;
+                    if (acc >= half) break;
+                }
+                const uint32_t pivot = ids[(size_t)cutpos];  // ids >= pivot go right
+                std::vector<RawRat> left, right;
+                for (const RawRat& a : part) ((by_user ? a.u : a.i) < pivot ? left : right).push_back(a);
+                std::vector<RawRat>().swap(part);
+                cut(left);
+                cut(right);
+            };
+            for (;;) {
+                const int64_t x = next_todo.fetch_add(1);
+                if (x >= (int64_t)todo.size() || failed.load()) break;
+                const int64_t c = todo[(size_t)x];
+                load_cell(c, sel);
+                pieces.clear();
+                cut(sel);
+                if (failed.load() || pieces.empty()) break;
+                co[(size_t)c] = std::move(pieces[0]);
+                extra[(size_t)c].assign(std::make_move_iterator(pieces.begin() + 1),
+                                        std::make_move_iterator(pieces.end()));
+            }
+        });
     }
     if (failed.load()) {
         err = fail_msg;
         return -1;
     }
-    lap("per-cell packing");
+    lap("  chunking");
 
-    // ---- concatenate in cell order; canonical order is round-major ----------
+    // ---- concatenate: first chunks at their cell index, the rest behind B*B ---
     out = Schedule{};
     out.geo = geo;
     out.B = B;
     out.W = W;
     out.nnz = n;
-    out.cells.resize((size_t)ncell);
-    out.subs.resize((size_t)(ncell * WW));
+    int64_t n_descs = ncell;
+    for (int64_t c = 0; c < ncell; ++c) n_descs += (int64_t)extra[(size_t)c].size();
+    if (n_descs > 0x7FFFFFFFll / WW) {
+        err = "build_schedule: too many chunks";
+        return -1;
+    }
+    out.cells.resize((size_t)n_descs);
+    out.subs.assign((size_t)(n_descs * WW) + 2, SubDesc{0, 0});  // +16 B: the staging DMA reads whole 16-byte units
+    std::vector<const CellOut*> by_desc((size_t)n_descs, nullptr);
     int64_t tot_rows = 0, tot_steps = 0;
     int64_t sched_cap = 0, rows_cap = 0;
-    for (int64_t c = 0; c < ncell; ++c) {
-        const CellOut& o = co[(size_t)c];
-        if (tot_rows > 0xFFFFFFFFll - (int64_t)o.rows.size() || tot_steps > 0xFFFFFFFFll - o.n_steps) {
-            err = "build_schedule: schedule exceeds 32-bit offsets";
-            return -1;
+    {
+        int64_t next_desc = ncell;
+        auto place = [&](int64_t d, const CellOut& o, uint32_t next) -> bool {
+            if (tot_rows > 0xFFFFFFFFll - (int64_t)o.rows.size() || tot_steps > 0xFFFFFFFFll - o.n_steps) return false;
+            CellDesc cdsc{};
+            cdsc.row_off = (uint32_t)tot_rows;
+            cdsc.ent_off = (uint32_t)tot_steps;
+            cdsc.n_steps = o.n_steps | (o.has_run ? kCellCritical : 0u);
+            cdsc.nu = (uint16_t)o.nu;
+            cdsc.ni = (uint16_t)o.ni;
+            cdsc.next = next;
+            out.cells[(size_t)d] = cdsc;
+            by_desc[(size_t)d] = &o;
+            for (int x = 0; x < WW; ++x)
+                out.subs[(size_t)(d * WW + x)] = o.subs.empty() ? SubDesc{0, 0} : o.subs[(size_t)x];
+            tot_rows += (int64_t)o.rows.size();
+            tot_steps += o.n_steps;
+            if (o.n_steps != 0) {
+                sched_cap = std::max(sched_cap, sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps));
+                rows_cap = std::max(rows_cap, rows_bytes_for(geo, (int)(o.nu + o.ni)));
+            }
+            return true;
+        };
+        for (int64_t c = 0; c < ncell; ++c) {
+            const std::vector<CellOut>& ex = extra[(size_t)c];
+            bool ok = place(c, co[(size_t)c], ex.empty() ? 0u : (uint32_t)next_desc);
+            int64_t nnz_c = (int64_t)co[(size_t)c].order.size(), rows_c = (int64_t)co[(size_t)c].rows.size();
+            int64_t crit_c = co[(size_t)c].crit;
+            for (size_t x = 0; ok && x < ex.size(); ++x) {
+                ok = place(next_desc, ex[x], x + 1 < ex.size() ? (uint32_t)(next_desc + 1) : 0u);
+                ++next_desc;
+                nnz_c += (int64_t)ex[x].order.size();
+                rows_c = std::max(rows_c, (int64_t)ex[x].rows.size());
+                crit_c += ex[x].crit;
+            }
+            if (!ok) {
+                err = "build_schedule: schedule exceeds 32-bit offsets";
+                return -1;
+            }
+            if (!ex.empty()) out.split_cells++;
+            out.max_cell_nnz = std::max(out.max_cell_nnz, nnz_c);
+            out.max_cell_rows = std::max(out.max_cell_rows, rows_c);
+            out.max_cell_steps = std::max(out.max_cell_steps, crit_c);
         }
-        CellDesc d;
-        d.row_off = (uint32_t)tot_rows;
-        d.ent_off = (uint32_t)tot_steps;
-        d.n_steps = o.n_steps | (o.has_run ? kCellCritical : 0u);
-        d.nu = (uint16_t)o.nu;
-        d.ni = (uint16_t)o.ni;
-        out.cells[(size_t)c] = d;
-        for (int x = 0; x < WW; ++x)
-            out.subs[(size_t)(c * WW + x)] = o.subs.empty() ? SubDesc{0, 0} : o.subs[(size_t)x];
-        tot_rows += (int64_t)o.rows.size();
-        tot_steps += o.n_steps;
-        sched_cap = std::max(sched_cap, sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps));
-        rows_cap = std::max(rows_cap, rows_bytes_for(geo, (int)(o.nu + o.ni)));
-        out.max_cell_nnz = std::max<int64_t>(out.max_cell_nnz, (int64_t)o.order.size());
-        out.max_cell_rows = std::max<int64_t>(out.max_cell_rows, (int64_t)o.rows.size());
-        out.max_cell_steps = std::max<int64_t>(out.max_cell_steps, o.crit);
     }
     lap("  offsets");
     {
+        sched_cap = std::max(sched_cap, min_sched);
+        rows_cap = std::max(rows_cap, min_rows);
         const int64_t need = 16 + 2 * sched_cap + rows_cap;
         if (need > prm.lds_budget) {
-            err = "lds: the largest cell needs " + std::to_string(need) + " bytes of LDS (budget " +
-                  std::to_string(prm.lds_budget) + "); use more blocks";
-            out.lds_bytes = (int)std::min<int64_t>(need, 0x7FFFFFFF);  // tells build_schedule_auto how far off it was
+            err = "build_schedule: internal error, chunks need " + std::to_string(need) + " bytes of LDS (budget " +
+                  std::to_string(prm.lds_budget) + ")";
             return -1;
         }
         out.lds_bytes = (int)((need + 15) & ~(int64_t)15);
@@ -569,9 +797,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         auto copier = [&]() {
             for (;;) {
                 const int64_t c = nc.fetch_add(64);
-                if (c >= ncell) break;
-                for (int64_t x = c; x < std::min<int64_t>(c + 64, ncell); ++x) {
-                    const CellOut& o = co[(size_t)x];
+                if (c >= n_descs) break;
+                for (int64_t x = c; x < std::min<int64_t>(c + 64, n_descs); ++x) {
+                    const CellOut& o = *by_desc[(size_t)x];
                     const CellDesc& d = out.cells[(size_t)x];
                     if (!o.rows.empty())
                         std::memcpy(&out.rows[d.row_off], o.rows.data(), o.rows.size() * sizeof(uint32_t));
@@ -594,12 +822,17 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         int64_t worst = 0;
         for (int b = 0; b < B; ++b) {
             const int64_t c = (int64_t)b * B + (b + rd) % B;
-            const CellOut& o = co[(size_t)c];
             out.cell_ptr[(size_t)((int64_t)rd * B + b)] = pos;
-            if (!o.order.empty())
-                std::memcpy(&out.order[(size_t)pos], o.order.data(), o.order.size() * sizeof(int64_t));
-            pos += (int64_t)o.order.size();
-            worst = std::max(worst, o.crit);
+            int64_t crit_c = 0;
+            auto append = [&](const CellOut& o) {
+                if (!o.order.empty())
+                    std::memcpy(&out.order[(size_t)pos], o.order.data(), o.order.size() * sizeof(int64_t));
+                pos += (int64_t)o.order.size();
+                crit_c += o.crit;
+            };
+            append(co[(size_t)c]);
+            for (const CellOut& o : extra[(size_t)c]) append(o);
+            worst = std::max(worst, crit_c);
         }
         out.sum_round_steps += worst;
     }
@@ -623,53 +856,53 @@ int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, con
         W = 4;
         while (W > 1 && (int64_t)W * 8 > minrows) W >>= 1;
     }
-    const bool autoB = prm.B <= 0;
-    int B = prm.B;
-    if (autoB) {
-        // rows a cell may hold in LDS, leaving a tenth for step entries
-        const double cap_rows = (double)prm.lds_budget * 0.9 / geo.rowbytes - 2.0 * geo.G;
-        // a cell of m ratings touches at most 2m rows, typically ~1.1m
-        const double target_nnz = std::max(16.0, 0.6 * cap_rows);
-        double best = std::ceil(std::sqrt((double)std::max<int64_t>(n, 1) / target_nnz));
-        int64_t bb = (int64_t)best;
-        if (bb <= prm.n_cu) {
+    if (prm.B <= 0) {
+        // Cost model of one epoch of the persistent kernel with m workgroups per CU (each gets 1/m
+        // of the LDS): B rounds, ceil(B / (m * CUs)) cells per workgroup per round, a fixed latency
+        // per cell (drain, gather, tile hand-off, scatter) plus the cell's share of the steps.  The
+        // typical cell has to fit the LDS share (over-full cells are chunked); within one pass count
+        // fewer, fuller cells win, so only the smallest feasible B of each m competes.
+        const double full = (double)prm.lds_budget + 512.0;           // the CU's LDS
+        const double cyc_step = 180.0 + 2.0 * geo.L;                  // ~ cycles of one step of one wave
+        const double per_rating = cyc_step / (double)(W * geo.G);     // cycles, all waves busy
+        const double overhead = 11000.0;                              // cycles per cell (~5 us)
+        const int64_t lim = std::max<int64_t>(1, minrows / W);
+        double best_cost = -1;
+        int best_B = 1, best_budget = prm.lds_budget;
+        for (int m = 1; m <= 4; ++m) {
+            const int budget = (int)(full / m) - 512;
+            // rows a cell may hold, leaving a tenth for step entries
+            const double cap_rows = (double)budget * 0.9 / geo.rowbytes - 2.0 * geo.G;
+            if (cap_rows < 8.0) break;
+            // a cell of x ratings touches at most 2x rows, typically ~1.1x
+            const double target_nnz = std::max(16.0, 0.6 * cap_rows);
+            int64_t bb = (int64_t)std::ceil(std::sqrt((double)std::max<int64_t>(n, 1) / target_nnz));
+            const int64_t np = (int64_t)prm.n_cu * m;
             bb = (bb + 7) / 8 * 8;
-            if (bb > prm.n_cu) bb = prm.n_cu;
             // a few more blocks than strictly needed keeps every CU busy
-            if (bb > prm.n_cu * 0.7) bb = prm.n_cu;
-        } else {
-            bb = (bb + prm.n_cu - 1) / prm.n_cu * prm.n_cu;
-        }
-        const int64_t lim = std::max<int64_t>(1, minrows / W);
-        if (bb > lim) bb = lim;
-        if (bb < 1) bb = 1;
-        B = (int)bb;
-    }
-    for (int attempt = 0; attempt < 6; ++attempt) {
-        prm.B = B;
-        prm.W = W;
-        const int rc = build_schedule(prm, u, i, r, orig, n, out, err);
-        if (rc == 0) return 0;
-        if (!autoB || err.compare(0, 4, "lds:") != 0) return rc;
-        // the rows of the offending cell shrink roughly like 1/B: jump straight to a B that fits
-        int64_t nb = B <= prm.n_cu / 2 ? (int64_t)B * 2 : ((int64_t)B / prm.n_cu + 1) * prm.n_cu;
-        if (out.lds_bytes > prm.lds_budget) {
-            const double ratio = (double)out.lds_bytes / (double)prm.lds_budget * 1.08;
-            int64_t want = (int64_t)std::ceil((double)B * ratio);
-            want = want <= prm.n_cu ? (want + 7) / 8 * 8 : (want + prm.n_cu - 1) / prm.n_cu * prm.n_cu;
-            nb = std::max(nb, want);
-        }
-        const int64_t lim = std::max<int64_t>(1, minrows / W);
-        if (nb > lim) {
-            if (W > 1) {
-                W >>= 1;
-                continue;
+            if (bb <= np && bb > np * 0.7) bb = np;
+            if (bb > lim) bb = lim;
+            if (bb < 1) bb = 1;
+            const double passes = std::ceil((double)bb / (double)np);
+            const double contention = 1.0 + 0.15 * (m - 1);
+            const double cost = (double)bb * passes *
+                                (overhead + contention * per_rating * (double)n / ((double)bb * (double)bb));
+            if (best_cost < 0 || cost < best_cost * 0.97) {  // prefer fewer workgroups per CU on near ties
+                best_cost = cost;
+                best_B = (int)bb;
+                best_budget = budget;
             }
-            return rc;
+            if (m == 1 && bb <= prm.n_cu) break;  // one pass with the whole LDS: nothing to gain
         }
-        B = (int)nb;
+        prm.B = best_B;
+        prm.lds_budget = best_budget;
     }
-    return -1;
+    prm.W = W;
+    for (;;) {
+        const int rc = build_schedule(prm, u, i, r, orig, n, out, err);
+        if (rc == 0 || err.compare(0, 4, "lds:") != 0 || prm.W <= 1) return rc;
+        prm.W >>= 1;  // smaller sub-cell tables and step groups
+    }
 }
 
 }  // namespace mfsgd

@@ -43,15 +43,22 @@ int64_t sched_bytes_for(const Geometry& geo, int W, int nrows, int64_t n_steps);
 int64_t rows_bytes_for(const Geometry& geo, int nrows);
 
 // Device-facing records (layout shared with kernels.hip).
+//
+// A cell whose LDS image would not fit is cut into CHUNKS: disjoint subsets of its users
+// (or items), each a complete little cell with its own row list, sub-cell table and steps.
+// A workgroup runs the chunks of a cell back to back (rows are stored and gathered again
+// between them); chunk order is part of the canonical order.  descs[c] for c < B*B is the
+// first chunk of cell c; further chunks live behind B*B and are linked through `next`.
 struct CellDesc {
-    uint32_t row_off;  // first entry of this cell in rows[]
-    uint32_t ent_off;  // first step of this cell (entries index = step * G + slot)
-    uint32_t n_steps;  // steps over all sub-cells; bit 31: latency-critical cell (it carries a long
-                       // per-row chain): the persistent kernel publishes its tile before anything else
+    uint32_t row_off;  // first entry of this chunk in rows[]
+    uint32_t ent_off;  // first step of this chunk (entries index = step * G + slot)
+    uint32_t n_steps;  // steps over all sub-cells; bit 31: the chunk carries a register-resident run
     uint16_t nu;       // distinct users  -> LDS slots [0, nu)
     uint16_t ni;       // distinct items  -> LDS slots [nu, nu + ni)
+    uint32_t next;     // index of the cell's next chunk, 0 = this is the last one
+    uint32_t rsv[3];
 };
-static_assert(sizeof(CellDesc) == 16, "CellDesc layout");
+static_assert(sizeof(CellDesc) == 32, "CellDesc layout");
 constexpr uint32_t kCellCritical = 0x80000000u;
 
 struct SubDesc {
@@ -88,27 +95,28 @@ struct Schedule {
     int64_t nnz = 0;
     int lds_bytes = 0;   // 16 + 2 * sched_cap + largest rows image
     int sched_cap = 0;   // bytes of one schedule buffer (largest cell, multiple of 16)
-    std::vector<CellDesc> cells;    // B*B, index ub*B + it
-    std::vector<uint32_t> rows;     // per cell: nu user rows then ni item rows
-    std::vector<SubDesc> subs;      // (cell*W + s)*W + w
-    std::vector<Entry> entries;     // (cell.ent_off + step)*G + slot
+    std::vector<CellDesc> cells;    // chunk descriptors: [0, B*B) first chunks (index ub*B + it), then the rest
+    std::vector<uint32_t> rows;     // per chunk: nu user rows then ni item rows
+    std::vector<SubDesc> subs;      // (desc*W + s)*W + w
+    std::vector<Entry> entries;     // (desc.ent_off + step)*G + slot
     std::vector<int64_t> order;     // canonical order -> caller's rating index
     std::vector<int64_t> cell_ptr;  // B*B+1, round-major: rd*B + b
     // statistics
     int64_t total_steps = 0, total_rows = 0;
     int64_t max_cell_nnz = 0, max_cell_rows = 0, max_cell_steps = 0, sum_round_steps = 0;
+    int64_t split_cells = 0;  // cells cut into more than one chunk
     double build_seconds = 0;
     bool device_ingest = false;  // degrees + bucket order came from the GPU
 };
 
 // u/i are row indices into P and into this partition's Q block; orig[j] is the
 // caller-visible index of rating j (nullptr = j itself).
-// Returns 0, or -1 with `err` set (err begins with "lds:" when only the LDS
-// budget was exceeded and a larger B may succeed).
+// Returns 0, or -1 with `err` set.  Cells too large for the LDS budget are chunked, so the
+// budget alone never makes a schedule fail.
 int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, const float* r,
                    const int64_t* orig, int64_t n, Schedule& out, std::string& err);
 
-// Picks B and W when they are 0 and retries with more blocks on "lds:" errors.
+// Picks B, W and the LDS budget (workgroups per CU) when B / W are 0.
 int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, const float* r,
                         const int64_t* orig, int64_t n, Schedule& out, std::string& err);
 

@@ -196,10 +196,10 @@ class MatrixFactorizationSGD:
         return order, cell_ptr
 
     def debug_schedule(self, part=0):
-        """Device-facing schedule arrays (cells, rows, subs, entries) as uint32 arrays."""
+        """Device-facing schedule arrays (chunk descriptors, rows, subs, entries) as uint32 arrays."""
         n = [C.c_int64() for _ in range(4)]
         self._check(self._lib.mfsgd_debug_schedule_sizes(self._handle(), int(part), *[C.byref(x) for x in n]))
-        cells = np.zeros((n[0].value, 4), np.uint32)
+        cells = np.zeros((n[0].value, 8), np.uint32)
         rows = np.zeros(n[1].value, np.uint32)
         subs = np.zeros((n[2].value, 2), np.uint32)
         entries = np.zeros((n[3].value, 4), np.uint32)

@@ -16,13 +16,28 @@ def replay_epoch(oracle, P, Q, k, lr, lam, sched, B, W, G, L):
     cells, rows, subs, entries = sched
     for rd in range(B):
         for b in range(B):
-            cell = b * B + (b + rd) % B
-            row_off, ent_off, n_steps, nuni = (int(v) for v in cells[cell])
-            n_steps &= 0x7FFFFFFF  # bit 31: "latency-critical cell" hint for the persistent kernel
+            # a cell is a chain of chunks (descriptor word 4 = next chunk, 0 = last), run back to back
+            chain, cell = [], b * B + (b + rd) % B
+            while True:
+                chain.append(cell)
+                cell = int(cells[cell][4])
+                if cell == 0:
+                    break
+                assert cell >= B * B, "chunk links must point behind the first-chunk table"
+            for cell in chain:
+                _replay_chunk(oracle, P, Q, k, lr, lam, sched, cell, W, G, L)
+
+
+def _replay_chunk(oracle, P, Q, k, lr, lam, sched, cell, W, G, L):
+    cells, rows, subs, entries = sched
+    if True:
+        if True:
+            row_off, ent_off, n_steps, nuni = (int(v) for v in cells[cell][:4])
+            n_steps &= 0x7FFFFFFF  # bit 31: "carries a run" hint
             nu, ni = nuni & 0xFFFF, nuni >> 16
             nrows = nu + ni
             if nrows == 0:
-                continue
+                return
             ids = rows[row_off:row_off + nrows]
             lds = np.zeros((nrows + 2 * G, k), np.float32)
             lds[:nu] = P[ids[:nu]]

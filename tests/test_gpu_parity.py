@@ -104,6 +104,55 @@ def test_more_blocks_than_resident_workgroups(mf, oracle):
     assert info["blocks"] == 300
 
 
+# ---- chunked cells: cells larger than the LDS image are cut into chunks --------------------------
+@pytest.mark.parametrize("k,B,W,n", [(256, 1, 2, 900), (128, 2, 4, 4000), (64, 1, 4, 4000), (200, 3, 1, 3000),
+                                     (64, 4, 4, 60000)])
+def test_chunked_cells(mf, oracle, k, B, W, n):
+    rng = np.random.default_rng(k + B)
+    U, I = 900, 800
+    key = rng.choice(U * I, n, replace=False)
+    _, info = _run(mf, oracle, U, I, k, key // I, key % I, rng.random(n) * 4 + 1, epochs=2, blocks=B, waves=W)
+    assert info["split_cells"] >= 1 and info["chunks"] > B * B
+
+
+def test_chunked_cells_round_launch_equals_persistent(mf, oracle):
+    from mfsgd_amd import _lib
+
+    rng = np.random.default_rng(77)
+    U, I, n = 3000, 400, 40000
+    wgt = 1.0 / (np.arange(I) + 3.0)
+    key = np.unique(rng.integers(0, U, n).astype(np.int64) * I + rng.choice(I, n, p=wgt / wgt.sum()))
+    u, i, r = key // I, key % I, rng.random(key.size) * 4 + 1
+    outs = []
+    for flags in (0, _lib.FLAG_ROUND_LAUNCH):
+        with mf.MatrixFactorizationSGD(U, I, 128, LR, LAM, 5, blocks=8, waves=4, flags=flags) as m:
+            rm = m.train(u, i, r, 2)
+            assert m.schedule_info()["split_cells"] >= 1
+            outs.append((m.get_factors(), rm))
+    assert np.array_equal(outs[0][0][0], outs[1][0][0]) and np.array_equal(outs[0][0][1], outs[1][0][1])
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-9)
+    _run(mf, oracle, U, I, 128, u, i, r, epochs=2, blocks=8, waves=4)
+
+
+def test_chunked_cells_with_more_blocks_than_workgroups(mf, oracle):
+    """Skewed items at k = 256 and B = 320 (> resident workgroups): chunk chains inside a multi-pass ring."""
+    rng = np.random.default_rng(320)
+    U, I, n = 20000, 3000, 400000
+    wgt = 1.0 / (np.arange(I) + 2.0)
+    key = np.unique(rng.integers(0, U, n).astype(np.int64) * I + rng.choice(I, n, p=wgt / wgt.sum()))
+    _, info = _run(mf, oracle, U, I, 256, key // I, key % I, rng.random(key.size) * 4 + 1, epochs=2, blocks=320,
+                   waves=4)
+    assert info["blocks"] == 320
+
+
+def test_auto_blocks_large_k_shares_the_cu(mf, oracle):
+    """k = 128 with enough ratings that one pass needs more than 256 blocks: the scheduler picks a
+    smaller LDS image so that several workgroups share a CU (or several passes), and stays exact."""
+    w = mf.synth.workload("cfg3_netflix", scale=0.2)
+    _, info = _run(mf, oracle, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"], epochs=1)
+    assert info["blocks"] > 256 and info["lds_bytes"] <= 80 * 1024 and info["split_cells"] > 0
+
+
 def test_round_launch_path_equals_persistent(mf, oracle):
     from mfsgd_amd import _lib
 

@@ -160,3 +160,45 @@ def test_fuzz_schedules_replay_exactly(mf, oracle):
         np.testing.assert_array_equal(Qe, Q)
         ok += 1
     assert ok >= 30
+
+
+# ---- chunked cells: a cell whose LDS image is too large is cut into chunks ---------------------
+@pytest.mark.parametrize("k,B,W,n", [(256, 1, 2, 700), (128, 2, 4, 2500), (64, 1, 4, 2500), (200, 3, 1, 2000)])
+def test_oversize_cells_are_chunked(mf, oracle, k, B, W, n):
+    rng = np.random.default_rng(k + B)
+    U, I = 900, 800
+    key = rng.choice(U * I, n, replace=False)
+    info = _check(mf, oracle, U, I, k, key // I, key % I, rng.random(n) * 4 + 1, blocks=B, waves=W)
+    assert info["blocks"] == B
+    assert info["split_cells"] >= 1 and info["chunks"] > B * B
+    assert info["lds_bytes"] <= 160 * 1024 - 512
+
+
+def test_chunk_split_by_items_and_by_users(mf, oracle):
+    # one user, many items: only the item side can be cut; and the mirror image
+    n = 400
+    info = _check(mf, oracle, 1, n, 256, [0] * n, list(range(n)), np.arange(n) * 0.01, blocks=1, waves=1)
+    assert info["split_cells"] == 1 and info["chunks"] >= 3
+    info = _check(mf, oracle, n, 1, 256, list(range(n)), [0] * n, np.arange(n) * 0.01, blocks=1, waves=1)
+    assert info["split_cells"] == 1 and info["chunks"] >= 3
+
+
+def test_chunks_leave_fitting_schedules_alone(mf):
+    # a schedule that fits is not cut, whatever else changed: chunks == cells
+    w = mf.synth.workload("cfg1_ml100k", scale=0.5)
+    with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 3) as m:
+        m.set_ratings(w["u"], w["i"], w["r"])
+        info = m.schedule_info()
+    assert info["split_cells"] == 0 and info["chunks"] == info["blocks"] ** 2
+
+
+def test_chunked_hot_item_at_large_k(mf, oracle):
+    # skewed popularity at k = 128 with few blocks: the hot item's cells overflow, the rest do not
+    rng = np.random.default_rng(9)
+    U, I, n = 3000, 400, 30000
+    wgt = 1.0 / (np.arange(I) + 3.0)
+    ii = rng.choice(I, n, p=wgt / wgt.sum())
+    uu = rng.integers(0, U, n)
+    key = np.unique(uu.astype(np.int64) * I + ii)
+    info = _check(mf, oracle, U, I, 128, key // I, key % I, rng.random(key.size) * 4 + 1, blocks=8, waves=4)
+    assert info["split_cells"] >= 1
