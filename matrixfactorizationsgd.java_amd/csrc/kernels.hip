@@ -201,6 +201,16 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
     rq = make_float4(q[0], q[1], q[2], q[3]);
 }
 
+// A chunk descriptor through the scalar path: the index is the same in every lane (it comes from
+// workgroup-uniform counters and from descriptors loaded this way), which the compiler cannot see
+// once it has been through memory -- pin it to an SGPR so that the load is an s_load and the
+// descriptor lives in SGPRs (it is live across the rating loops, where VGPRs are scarce).
+__device__ __forceinline__ CellDesc load_desc(const CellDesc* __restrict__ cells, unsigned idx) {
+    idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+    asm volatile("" : "+s"(idx));
+    return cells[idx];
+}
+
 // Everything one workgroup does with one cell, phase by phase.  Shared by the
 // per-round kernel, the SSE pass and the persistent epoch kernel.
 //
@@ -525,7 +535,7 @@ cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __rest
     }
     double acc = 0.0;
     for (;;) {
-        const CellDesc cd = cells[cell];
+        const CellDesc cd = load_desc(cells, (unsigned)cell);
         cx.bind(cd, smem, 0, sched_cap);
         if (cx.nrows == 0) break;  // uniform over the workgroup; an empty cell has no further chunk
         cx.stage_schedule(cd, cell, rows, subs, entries);
@@ -642,9 +652,9 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     // Software pipeline over the list: descriptors are fetched two items ahead (registers),
     // schedules one item ahead (LDS-DMA into the other schedule buffer).
     Item it0{0, wg, cell_of(0, wg), true};
-    CellDesc cd = cells[it0.idx];
+    CellDesc cd = load_desc(cells, it0.idx);
     Item it1 = next_item(it0, cd);
-    CellDesc cd1 = it1.R < n_rounds ? cells[it1.idx] : cd;
+    CellDesc cd1 = it1.R < n_rounds ? load_desc(cells, it1.idx) : cd;
     int buf = 0;
     cx.bind(cd, smem, buf, sched_cap);
     cx.stage_schedule(cd, (int)it0.idx, rows, subs, entries);  // the first one synchronously
@@ -699,12 +709,12 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         wg_barrier();
         mark(2);  // the other waves' arrival
         if (ctl[0] != 0) return;  // uniform: some workgroup timed out
-        // descriptor used two iterations from now: issued here so that no wait of this
-        // iteration's latency-critical part (the drain above, the tile poll) sits behind it
         const Item it2 = next_item(it1, cd1);
-        if (it2.R < n_rounds) cd2 = cells[it2.idx];
+        if (work) cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
+        // descriptor used two iterations from now: a scalar load issued here, behind every gather of
+        // this iteration, so that it completes in the shadow of the wait for the rows
+        if (it2.R < n_rounds) cd2 = load_desc(cells, it2.idx);
         if (work) {
-            cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows (and the prefetched schedule) have landed
             wg_barrier();
             mark(3);  // tile rows (and own rows, and the next schedule) landed

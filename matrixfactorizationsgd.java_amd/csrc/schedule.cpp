@@ -857,45 +857,32 @@ int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, con
         while (W > 1 && (int64_t)W * 8 > minrows) W >>= 1;
     }
     if (prm.B <= 0) {
-        // Cost model of one epoch of the persistent kernel with m workgroups per CU (each gets 1/m
-        // of the LDS): B rounds, ceil(B / (m * CUs)) cells per workgroup per round, a fixed latency
-        // per cell (drain, gather, tile hand-off, scatter) plus the cell's share of the steps.  The
-        // typical cell has to fit the LDS share (over-full cells are chunked); within one pass count
-        // fewer, fuller cells win, so only the smallest feasible B of each m competes.
-        const double full = (double)prm.lds_budget + 512.0;           // the CU's LDS
-        const double cyc_step = 180.0 + 2.0 * geo.L;                  // ~ cycles of one step of one wave
-        const double per_rating = cyc_step / (double)(W * geo.G);     // cycles, all waves busy
-        const double overhead = 11000.0;                              // cycles per cell (~5 us)
-        const int64_t lim = std::max<int64_t>(1, minrows / W);
-        double best_cost = -1;
-        int best_B = 1, best_budget = prm.lds_budget;
-        for (int m = 1; m <= 4; ++m) {
-            const int budget = (int)(full / m) - 512;
-            // rows a cell may hold, leaving a tenth for step entries
-            const double cap_rows = (double)budget * 0.9 / geo.rowbytes - 2.0 * geo.G;
-            if (cap_rows < 8.0) break;
-            // a cell of x ratings touches at most 2x rows, typically ~1.1x
-            const double target_nnz = std::max(16.0, 0.6 * cap_rows);
-            int64_t bb = (int64_t)std::ceil(std::sqrt((double)std::max<int64_t>(n, 1) / target_nnz));
-            const int64_t np = (int64_t)prm.n_cu * m;
+        // One workgroup per CU with the whole LDS (measured: sharing a CU between two or three
+        // smaller workgroups loses more to the longer hand-off chain than it gains in overlap).
+        // rows a cell may hold in LDS, leaving a tenth for step entries
+        const double cap_rows = (double)prm.lds_budget * 0.9 / geo.rowbytes - 2.0 * geo.G;
+        // a cell of x ratings touches at most 2x rows, typically ~1.1x
+        const double nn = (double)std::max<int64_t>(n, 1);
+        int64_t bb = (int64_t)std::ceil(std::sqrt(nn / std::max(16.0, 0.6 * cap_rows)));
+        if (bb <= prm.n_cu) {
             bb = (bb + 7) / 8 * 8;
+            if (bb > prm.n_cu) bb = prm.n_cu;
             // a few more blocks than strictly needed keeps every CU busy
-            if (bb <= np && bb > np * 0.7) bb = np;
-            if (bb > lim) bb = lim;
-            if (bb < 1) bb = 1;
-            const double passes = std::ceil((double)bb / (double)np);
-            const double contention = 1.0 + 0.15 * (m - 1);
-            const double cost = (double)bb * passes *
-                                (overhead + contention * per_rating * (double)n / ((double)bb * (double)bb));
-            if (best_cost < 0 || cost < best_cost * 0.97) {  // prefer fewer workgroups per CU on near ties
-                best_cost = cost;
-                best_B = (int)bb;
-                best_budget = budget;
-            }
-            if (m == 1 && bb <= prm.n_cu) break;  // one pass with the whole LDS: nothing to gain
+            if (bb > prm.n_cu * 0.7) bb = prm.n_cu;
+        } else {
+            // Several cells per workgroup and round.  Cells that overflow are chunked, so B need not
+            // grow until the largest cell fits: aim the typical cell at half the LDS rows and take a
+            // multiple of half the CU count -- the lower one when it is within 15 % (measured on
+            // k = 128 / 256 at 20 M ratings: fewer, fuller cells win until chunking hits the hot items).
+            bb = (int64_t)std::ceil(std::sqrt(nn / std::max(16.0, 0.5 * cap_rows)));
+            const int64_t half = std::max<int64_t>(1, prm.n_cu / 2);
+            const int64_t lo = std::max<int64_t>(prm.n_cu, bb / half * half);
+            bb = (double)bb <= 1.15 * (double)lo ? lo : lo + half;
         }
-        prm.B = best_B;
-        prm.lds_budget = best_budget;
+        const int64_t lim = std::max<int64_t>(1, minrows / W);
+        if (bb > lim) bb = lim;
+        if (bb < 1) bb = 1;
+        prm.B = (int)bb;
     }
     prm.W = W;
     for (;;) {

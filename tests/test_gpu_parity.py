@@ -145,12 +145,12 @@ def test_chunked_cells_with_more_blocks_than_workgroups(mf, oracle):
     assert info["blocks"] == 320
 
 
-def test_auto_blocks_large_k_shares_the_cu(mf, oracle):
-    """k = 128 with enough ratings that one pass needs more than 256 blocks: the scheduler picks a
-    smaller LDS image so that several workgroups share a CU (or several passes), and stays exact."""
+def test_auto_blocks_large_k_multi_pass(mf, oracle):
+    """k = 128 at 20 M ratings: more blocks than CUs, so every workgroup runs several cells per round
+    (and B is a multiple of half the CU count rather than whatever makes the largest cell fit)."""
     w = mf.synth.workload("cfg3_netflix", scale=0.2)
     _, info = _run(mf, oracle, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"], epochs=1)
-    assert info["blocks"] > 256 and info["lds_bytes"] <= 80 * 1024 and info["split_cells"] > 0
+    assert info["blocks"] > 256 and info["blocks"] % 128 == 0
 
 
 def test_round_launch_path_equals_persistent(mf, oracle):

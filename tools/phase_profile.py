@@ -1,0 +1,31 @@
+"""Diagnostic: per-phase shader cycles of one persistent epoch (mfsgd_debug_epoch_profile).
+
+    python tools/phase_profile.py WORKLOAD SCALE [BLOCKS]
+"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import mfsgd_amd as mf  # noqa: E402
+
+name, scale = sys.argv[1], float(sys.argv[2])
+blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+w = mf.synth.workload(name, scale)
+with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], 0.01, 0.05, 3, blocks=blocks) as m:
+    m.set_ratings(w["u"], w["i"], w["r"])
+    m.init_factors()
+    info = m.schedule_info()
+    m.fit(1, rmse=False)
+    ms, _ = m.train_timed(5)
+    prof = m.debug_epoch_profile().astype(np.float64)
+names = ["drain+issue", "tile wait", "barrier", "tile gather", "ratings", "publish", "own store"]
+tot = prof.sum(axis=1)
+nnz = info['nnz']
+print(f"{name} x{scale}: B={info['blocks']} W={info['waves']} lds={info['lds_bytes']} chunks={info['chunks']} "
+      f"split={info['split_cells']} workgroups={prof.shape[0]} epoch={ms / 5:.3f} ms "
+      f"rate={nnz / (ms / 5) / 1e3:.0f} M/s")
+print("  phase cycles (mean over workgroups, share of the mean total %.0f):" % tot.mean())
+for k, nm in enumerate(names):
+    print(f"    {nm:12s} {prof[:, k].mean():12.0f}  {100 * prof[:, k].mean() / tot.mean():5.1f} %")
