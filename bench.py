@@ -76,13 +76,13 @@ def cpu_baseline(w, m, budget_s=12.0):
     }
 
 
-def read_traffic(k, nnz):
+def read_traffic(workload, k, nnz):
     """HBM bytes per launch from the committed rocprofv3 PMC summary, if one matches."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("k") == k and t.get("nnz") == nnz:
+        if t.get("workload") == workload and t.get("k") == k and t.get("nnz") == nnz:
             return t.get("hbm_bytes_per_launch")
     except Exception:
         pass
@@ -233,7 +233,7 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved_gbs / HBM_PEAK_GBS,
-        "traffic": read_traffic(k, nnz) if world == 1 else None,
+        "traffic": read_traffic(args.workload, k, nnz) if world == 1 else None,
         "bytes_per_update": bytes_per_update,
         "updates_per_launch": units_per_launch,
         "avg_launch_us": avg_launch_s * 1e6,

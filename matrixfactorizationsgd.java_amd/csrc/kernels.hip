@@ -775,8 +775,8 @@ sse_kernel(const float* __restrict__ P, const float* __restrict__ Q, const CellD
     int c = (int)blockIdx.x;
     double acc = 0.0;
     if (c < n_cells) {
-        CellDesc cd = cells[c];
-        CellDesc cd1 = c + stride < n_cells ? cells[c + stride] : cd;
+        CellDesc cd = load_desc(cells, (unsigned)c);
+        CellDesc cd1 = c + stride < n_cells ? load_desc(cells, (unsigned)(c + stride)) : cd;
         int buf = 0;
         cx.bind(cd, smem, buf, sched_cap);
         cx.stage_schedule(cd, c, rows, subs, entries);
@@ -789,7 +789,7 @@ sse_kernel(const float* __restrict__ P, const float* __restrict__ Q, const CellD
             if (c1 < n_cells) cx.prefetch_schedule(cd1, c1, smem, buf ^ 1, sched_cap, rows, subs, entries);
             if (cx.nrows != 0) cx.gather(P, Q, 0, cx.nrows);
             CellDesc cd2 = cd1;
-            if (c2 < n_cells) cd2 = cells[c2];
+            if (c2 < n_cells) cd2 = load_desc(cells, (unsigned)c2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows and the next schedule have landed
             wg_barrier();
             if (cx.nrows != 0) cx.template apply<false>(0.f, 0.f, acc);
