@@ -42,7 +42,7 @@ typedef enum mfsgd_status {
     MFSGD_ERR_OOM = -4,         /* host or device allocation failed            */
     MFSGD_ERR_STATE = -5,       /* call order violated (e.g. train before set) */
     MFSGD_ERR_UNSUPPORTED = -6, /* e.g. k > MFSGD_MAX_K                        */
-    MFSGD_ERR_SCHEDULE = -7     /* no LDS-feasible schedule could be built     */
+    MFSGD_ERR_SCHEDULE = -7     /* schedule could not be built (bad index, 32-bit overflow) */
 } mfsgd_status;
 
 #define MFSGD_MAX_K 256
