@@ -329,19 +329,20 @@ def test_train_twice_and_new_ratings(mf, oracle):
 
 
 # ---- DSGD building blocks on one GPU (virtual devices) -------------------------------
-@pytest.mark.parametrize("G", [2, 4])
-def test_dsgd_virtual_devices(mf, oracle, G):
+@pytest.mark.parametrize("G,k,B", [(2, 64, 0), (4, 64, 0), (3, 256, 1)])  # the last one: every partition chunked
+def test_dsgd_virtual_devices(mf, oracle, G, k, B):
     import torch
 
     from tests.dsgd_common import LAM as DL, LR as DLR, SEED, rank_workload, sequential_dsgd
 
-    U_local, I, k, nnz, epochs = 500, 333, 64, 20000, 2
+    U_local, I, nnz, epochs = 500, 333, 20000, 2
     dev = torch.device("cuda", 0)
     trainers, data, blocks = [], [], []
     for g in range(G):
         u, i, r = rank_workload(g, U_local, I, nnz)
-        t = mf.MatrixFactorizationSGD(U_local, I, k, DLR, DL, SEED, n_parts=G)
+        t = mf.MatrixFactorizationSGD(U_local, I, k, DLR, DL, SEED, n_parts=G, blocks=B)
         t.set_ratings(u, i, r)
+        assert B == 0 or t.schedule_info(0)["split_cells"] >= 1
         t.init_p_offset(SEED, g * U_local)
         trainers.append(t)
         data.append((u, i, r))
