@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -140,10 +142,11 @@ int dev_alloc(mfsgd_handle* h, DevBuf& b, size_t bytes) {
 }
 
 template <class T>
-int upload(mfsgd_handle* h, DevBuf& b, const std::vector<T>& v) {
-    int rc = dev_alloc(h, b, v.size() * sizeof(T));
+int upload(mfsgd_handle* h, DevBuf& b, const T& v) {
+    using E = std::remove_reference_t<decltype(*v.data())>;
+    int rc = dev_alloc(h, b, v.size() * sizeof(E));
     if (rc) return rc;
-    if (!v.empty()) HIPCHK(h, hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!v.empty()) HIPCHK(h, hipMemcpy(b.p, v.data(), v.size() * sizeof(E), hipMemcpyHostToDevice));
     return MFSGD_OK;
 }
 
@@ -411,6 +414,14 @@ const char* mfsgd_last_error(const mfsgd_handle* h) { return h ? h->err.c_str() 
 int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const float* r, int64_t nnz) {
     if (!h) return MFSGD_ERR_INVALID_ARG;
     if (nnz < 0 || (nnz > 0 && (!u || !i || !r))) return fail(h, MFSGD_ERR_INVALID_ARG, "set_ratings: null array or negative nnz");
+    const bool trace = std::getenv("MFSGD_SCHED_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[set_ratings] %-25s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     try {
         // drop what an earlier call built (device copies included)
         if (h->device_ready) {
@@ -433,6 +444,7 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
             if (u[j] < 0 || u[j] >= h->cfg.n_users || i[j] < 0 || i[j] >= h->cfg.n_items)
                 return fail(h, MFSGD_ERR_INVALID_ARG, "set_ratings: rating " + std::to_string(j) + " has (u,i) = (" +
                                                           std::to_string(u[j]) + "," + std::to_string(i[j]) + ") out of range");
+        lap("release + range check");
         const int G = h->n_parts;
         h->parts.resize((size_t)G);
         // Ingestion (degree histograms, bucket order) runs on the GPU when there is one and the
@@ -448,6 +460,7 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
             DeviceIngest& d;
             ~IngestGuard() { destroy_device_ingest(d); }
         } ingest_guard{ingest};
+        lap("device ingest context");
         SchedParams prm;
         prm.ingest = ingest.ctx ? &ingest : nullptr;
         prm.U = h->cfg.n_users;
@@ -460,17 +473,27 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
         if (G == 1) {
             Part& p = h->parts[0];
             p.q_rows = h->cfg.n_items;
-            // which side carries the longest chain?
-            std::vector<int32_t> du((size_t)h->cfg.n_users, 0), di((size_t)h->cfg.n_items, 0);
-            for (int64_t j = 0; j < nnz; ++j) {
-                du[(size_t)u[j]]++;
-                di[(size_t)i[j]]++;
+            // rating counts per user and per item: on the device when it ingests, else here; they
+            // decide which side carries the longest chain and are handed on to the scheduler
+            std::vector<int64_t> du((size_t)h->cfg.n_users, 0), di((size_t)h->cfg.n_items, 0);
+            if (!(ingest.ctx && ingest.degrees &&
+                  ingest.degrees(ingest.ctx, u, i, nnz, h->cfg.n_users, h->cfg.n_items, du.data(), di.data()) == 0)) {
+                std::fill(du.begin(), du.end(), 0);
+                std::fill(di.begin(), di.end(), 0);
+                for (int64_t j = 0; j < nnz; ++j) {
+                    du[(size_t)u[j]]++;
+                    di[(size_t)i[j]]++;
+                }
             }
-            const int32_t mu = du.empty() ? 0 : *std::max_element(du.begin(), du.end());
-            const int32_t mi = di.empty() ? 0 : *std::max_element(di.begin(), di.end());
+            const int64_t mu = du.empty() ? 0 : *std::max_element(du.begin(), du.end());
+            const int64_t mi = di.empty() ? 0 : *std::max_element(di.begin(), di.end());
+            prm.validated = true;  // the loop above checked every (u, i)
+            lap("degrees + role decision");
             p.swapped = mu > mi;
             std::string err;
             int rc;
+            prm.degu = p.swapped ? di.data() : du.data();
+            prm.degi = p.swapped ? du.data() : di.data();
             if (p.swapped) {
                 prm.U = h->cfg.n_items;
                 prm.I = h->cfg.n_users;
@@ -508,6 +531,7 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
                     return fail(h, MFSGD_ERR_SCHEDULE, "partition " + std::to_string(g) + ": " + err);
             }
         }
+        lap("schedules");
         h->nnz_total = nnz;
         h->have_ratings = true;
         return MFSGD_OK;

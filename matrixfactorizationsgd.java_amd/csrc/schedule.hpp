@@ -21,6 +21,8 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -77,6 +79,49 @@ struct Entry {
 };
 static_assert(sizeof(Entry) == 16, "Entry layout");
 
+// Big flat arrays of the schedule: allocated without being cleared (a std::vector would
+// write 0.9 GB of zeros for 20 M ratings before the packer overwrites every byte).
+template <class T>
+class PodVec {
+public:
+    PodVec() = default;
+    PodVec(const PodVec&) = delete;
+    PodVec& operator=(const PodVec&) = delete;
+    PodVec(PodVec&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    PodVec& operator=(PodVec&& o) noexcept {
+        if (this != &o) {
+            std::free(p_);
+            p_ = o.p_;
+            n_ = o.n_;
+            o.p_ = nullptr;
+            o.n_ = 0;
+        }
+        return *this;
+    }
+    ~PodVec() { std::free(p_); }
+    // contents are unspecified afterwards (not preserved, not cleared)
+    void resize_uninit(size_t n) {
+        std::free(p_);
+        p_ = nullptr;
+        n_ = 0;
+        if (n) {
+            p_ = static_cast<T*>(std::malloc(n * sizeof(T)));
+            if (!p_) throw std::bad_alloc();
+            n_ = n;
+        }
+    }
+    T* data() { return p_; }
+    const T* data() const { return p_; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    T& operator[](size_t i) { return p_[i]; }
+    const T& operator[](size_t i) const { return p_[i]; }
+
+private:
+    T* p_ = nullptr;
+    size_t n_ = 0;
+};
+
 struct SchedParams {
     int32_t U = 0, I = 0;   // row counts of P and of this partition's Q block
     int k = 0;
@@ -87,6 +132,11 @@ struct SchedParams {
     int n_cu = 256;
     int threads = 0;        // 0 = hardware_concurrency
     const DeviceIngest* ingest = nullptr;  // optional: degrees and bucket order computed on the GPU
+    // optional: rating counts per P row / Q row the caller already has (skips that pass), and a
+    // promise that every (u, i) has been range-checked
+    const int64_t* degu = nullptr;
+    const int64_t* degi = nullptr;
+    bool validated = false;
 };
 
 struct Schedule {
@@ -96,10 +146,10 @@ struct Schedule {
     int lds_bytes = 0;   // 16 + 2 * sched_cap + largest rows image
     int sched_cap = 0;   // bytes of one schedule buffer (largest cell, multiple of 16)
     std::vector<CellDesc> cells;    // chunk descriptors: [0, B*B) first chunks (index ub*B + it), then the rest
-    std::vector<uint32_t> rows;     // per chunk: nu user rows then ni item rows
+    PodVec<uint32_t> rows;          // per chunk: nu user rows then ni item rows
     std::vector<SubDesc> subs;      // (desc*W + s)*W + w
-    std::vector<Entry> entries;     // (desc.ent_off + step)*G + slot
-    std::vector<int64_t> order;     // canonical order -> caller's rating index
+    PodVec<Entry> entries;          // (desc.ent_off + step)*G + slot
+    PodVec<int64_t> order;          // canonical order -> caller's rating index
     std::vector<int64_t> cell_ptr;  // B*B+1, round-major: rd*B + b
     // statistics
     int64_t total_steps = 0, total_rows = 0;
