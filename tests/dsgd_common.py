@@ -107,3 +107,30 @@ def fuzz_cases(n_cases, seed=2024, max_ratings=2500):
         B = int(rng.choice([0, 0, 1, 2, 3, 5]))
         yield dict(U=U, I=I, k=k, u=u.astype(np.int32), i=i.astype(np.int32), r=r, blocks=B, waves=W,
                    lr=float(rng.choice([0.01, 0.05])), lam=float(rng.choice([0.0, 0.05])))
+
+
+def fuzz_chunked_cases(n_cases, seed=4242, max_ratings=9000):
+    """Random problems sized so that cells overflow the LDS image and are chunked: large k, few
+    blocks, hundreds of rows per side, skew and repeated pairs included."""
+    rng = np.random.default_rng(seed)
+    for _ in range(n_cases):
+        U = int(rng.integers(150, 1200))
+        I = int(rng.integers(150, 1200))
+        n = int(rng.integers(max_ratings // 4, max_ratings))
+        if rng.random() < 0.6:
+            wu = 1.0 / (np.arange(U) + 1.0) ** rng.uniform(0.0, 1.2)
+            wi = 1.0 / (np.arange(I) + 1.0) ** rng.uniform(0.0, 1.2)
+            u = rng.choice(U, n, p=wu / wu.sum())
+            i = rng.choice(I, n, p=wi / wi.sum())
+        else:
+            u = rng.integers(0, U, n)
+            i = rng.integers(0, I, n)
+        if rng.random() < 0.7:
+            key = rng.permutation(np.unique(u.astype(np.int64) * I + i))
+            u, i = key // I, key % I
+        r = (rng.standard_normal(u.size) * 2 + 3).astype(np.float32)
+        k = int(rng.choice([64, 100, 128, 200, 256]))
+        W = int(rng.choice([1, 2, 4, 8]))
+        B = int(rng.choice([1, 1, 2, 3, 4]))
+        yield dict(U=U, I=I, k=k, u=u.astype(np.int32), i=i.astype(np.int32), r=r, blocks=B, waves=W,
+                   lr=float(rng.choice([0.01, 0.05])), lam=float(rng.choice([0.0, 0.05])))

@@ -236,6 +236,17 @@ def test_fuzz_random_problems(mf, oracle):
     assert ok >= 90
 
 
+def test_fuzz_chunked_problems(mf, oracle):
+    from tests.dsgd_common import fuzz_chunked_cases
+
+    split = 0
+    for c in fuzz_chunked_cases(30):
+        _, info = _run(mf, oracle, c["U"], c["I"], c["k"], c["u"], c["i"], c["r"], epochs=2, lr=c["lr"], lam=c["lam"],
+                       blocks=c["blocks"], waves=c["waves"])
+        split += info["split_cells"] > 0
+    assert split >= 15
+
+
 # ---- predict / factors / repeated training ------------------------------------------
 def test_predict_and_set_factors(mf, oracle):
     rng = np.random.default_rng(4)

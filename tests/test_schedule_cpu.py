@@ -202,3 +202,29 @@ def test_chunked_hot_item_at_large_k(mf, oracle):
     key = np.unique(uu.astype(np.int64) * I + ii)
     info = _check(mf, oracle, U, I, 128, key // I, key % I, rng.random(key.size) * 4 + 1, blocks=8, waves=4)
     assert info["split_cells"] >= 1
+
+
+def test_fuzz_chunked_schedules_replay_exactly(mf, oracle):
+    from tests.dsgd_common import fuzz_chunked_cases
+
+    split = 0
+    for c in fuzz_chunked_cases(6, seed=99, max_ratings=5000):
+        with mf.MatrixFactorizationSGD(c["U"], c["I"], c["k"], c["lr"], c["lam"], 3, blocks=c["blocks"],
+                                       waves=c["waves"]) as m:
+            m.set_ratings(c["u"], c["i"], c["r"])
+            info = m.schedule_info()
+            order, cell_ptr = m.order()
+            sched = m.debug_schedule()
+        assert oracle.check_block_schedule(c["u"], c["i"], c["U"], c["I"], order, cell_ptr, info["rounds"], info["blocks"]) == 0
+        P, Q = oracle.init_factors(c["U"], c["I"], c["k"], 3)
+        Pe, Qe = P.copy(), Q.copy()
+        oracle.sgd_pass_ordered(P, Q, c["u"], c["i"], c["r"], order, c["lr"], c["lam"])
+        args = (c["k"], c["lr"], c["lam"], sched, info["blocks"], info["waves"], info["slots"], info["group_lanes"])
+        if info["swapped"]:
+            replay_epoch(oracle, Qe, Pe, *args)
+        else:
+            replay_epoch(oracle, Pe, Qe, *args)
+        np.testing.assert_array_equal(Pe, P)
+        np.testing.assert_array_equal(Qe, Q)
+        split += info["split_cells"] > 0
+    assert split >= 3
