@@ -926,6 +926,22 @@ int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, con
         if (bb < 1) bb = 1;
         prm.B = (int)bb;
     }
+    if (prm.W <= 0 && W == 4 && prm.degu && prm.degi && n > 0) {
+        // Two waves per workgroup instead of four when the epoch is bound by one row's chain of
+        // dependent updates rather than by the amount of work: fewer sub-rounds (barriers) sit on
+        // that chain then, and the other waves would only wait.  Measured (MI355X): ML-20M shape
+        // k = 64 3.54 vs 3.64 ms, Netflix shape k = 128 / 20 M 10.1 vs 11.1 ms; but uniform
+        // popularity 2.94 vs 2.49 ms and a 10 M-rating DSGD partition 4.89 vs 4.50 ms -- hence the
+        // comparison of the chain (longest row x cycles per dependent step) with the per-workgroup
+        // work at two waves (cycles per rating fitted on the uniform workload) plus the per-cell latency.
+        const int64_t dmax = std::max(*std::max_element(prm.degu, prm.degu + prm.U),
+                                      *std::max_element(prm.degi, prm.degi + prm.I));
+        const double np = (double)std::min<int64_t>(prm.B, prm.n_cu);
+        const double passes = std::ceil((double)prm.B / (double)prm.n_cu);
+        const double t_chain = (double)dmax * (170.0 + 2.0 * geo.L);
+        const double t_rest2 = 48.0 * (4.0 / geo.G) * (double)n / np + 12000.0 * (double)prm.B * passes;
+        if (t_chain > 1.1 * t_rest2) W = 2;
+    }
     prm.W = W;
     for (;;) {
         const int rc = build_schedule(prm, u, i, r, orig, n, out, err);

@@ -1,6 +1,6 @@
 """Diagnostic: per-phase shader cycles of one persistent epoch (mfsgd_debug_epoch_profile).
 
-    python tools/phase_profile.py WORKLOAD SCALE [BLOCKS]
+    python tools/phase_profile.py WORKLOAD SCALE [BLOCKS [WAVES]]
 """
 import sys
 import time
@@ -12,8 +12,9 @@ import mfsgd_amd as mf  # noqa: E402
 
 name, scale = sys.argv[1], float(sys.argv[2])
 blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+waves = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 w = mf.synth.workload(name, scale)
-with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], 0.01, 0.05, 3, blocks=blocks) as m:
+with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], 0.01, 0.05, 3, blocks=blocks, waves=waves) as m:
     m.set_ratings(w["u"], w["i"], w["r"])
     m.init_factors()
     info = m.schedule_info()
