@@ -107,6 +107,28 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so /
+    libhsa-runtime64.so; libmfsgd.so is linked against the system ROCm's.  Both have the SONAME
+    libamdhip64.so.7, but torch asks for "libamdhip64.so", so when libmfsgd.so comes first the
+    process ends up with two runtimes -- and on some hosts whichever initialises second then sees
+    no GPU (measured here: hipGetDeviceCount() == 0 / "No HIP GPUs are available").  Loading
+    torch's copy first makes the dynamic loader resolve libmfsgd.so's dependency to it (SONAME
+    match), which is also what happens whenever `import torch` precedes this module.  torch itself
+    is not imported; without a torch installation nothing is done."""
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # a broken torch installation must not keep the library from loading
+        pass
+
+
 def load_library():
     """Loads libmfsgd.so.  Raises (never falls back) when it has not been built."""
     global _lib
@@ -118,6 +140,7 @@ def load_library():
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C matrixfactorizationsgd.java_amd/csrc` (there is no CPU fallback)"
         )
+    _share_torch_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
