@@ -7,7 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libmfsgd.so")
+    """The in-tree build; MFSGD_LIBRARY names another build of the same ABI (kernel experiments)."""
+    return os.environ.get("MFSGD_LIBRARY") or os.path.join(_HERE, "lib", "libmfsgd.so")
 
 
 class Config(C.Structure):

@@ -201,8 +201,6 @@ CellLaunch make_launch(const mfsgd_handle* h, const Part& p, float* Q) {
     a.rd = 0;
     a.grid = p.sched.B;
     a.lds_bytes = p.sched.lds_bytes;
-    a.split_off = p.sched.split_off;
-    a.split_steps = p.sched.split_steps;
     a.sched_cap = p.sched.sched_cap;
     a.lr = h->cfg.lr;
     a.c = 1.0f - h->cfg.lr * h->cfg.lambda;

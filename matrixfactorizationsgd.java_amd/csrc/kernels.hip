@@ -201,219 +201,6 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
     rq = make_float4(q[0], q[1], q[2], q[3]);
 }
 
-// ---- the same run, split between two waves ------------------------------------------------
-// The chain wave (run_loop_chain_asm) keeps what the next step depends on -- dot, s, the resident
-// q rows -- and posts s into a mailbox in LDS (one word per lane slot and step) instead of
-// computing and storing p'.  Its helper wave (run_loop_helper_asm), on another SIMD, follows a
-// step or so behind: it takes s from the mailbox, keeps its own copy of the resident q rows
-// (same operations in the same order, hence the same bits), computes p' = fma(s, q, ce*p) and
-// stores it, and resets the mailbox word to the "empty" pattern.  Valid only for runs in which no
-// p row occurs twice (the scheduler flags them: SubDesc.off bit 31), because the chain wave reads
-// p rows the helper may not have written yet otherwise.  The helper writes the q rows back at the
-// end of the run; the chain wave's copy is dropped.
-//   mb : LDS byte address of this wave's mailbox + 4 * lane slot (16 bytes per step)
-constexpr unsigned kMailEmpty = 0xFFFFFFFFu;  // never the bits of an s the arithmetic produces (a NaN with full payload); the asm spells it -1
-
-template <int EST>
-__device__ __forceinline__ void run_loop_chain_asm(const float4 rq, const unsigned ea, const unsigned rowbase,
-                                                   const unsigned mb, int pairs, const float lr) {
-    using f4 = __attribute__((ext_vector_type(4))) float;
-    const f4 q = {rq.x, rq.y, rq.z, rq.w};
-    const unsigned long long lead = 0x0001000100010001ull;  // lane 0 of each 16-lane slot
-    asm volatile(
-        "v_mov_b32 v138, %[ea]\n\t"
-        "v_mov_b32 v139, %[rb]\n\t"
-        "v_mov_b32 v144, %[mb]\n\t"
-        "ds_read_b32 v114, v138\n\t"
-        "ds_read_b64 v[116:117], v138 offset:8\n\t"
-        "ds_read_b32 v115, v138 offset:%c[e1]\n\t"
-        "v_mov_b32 v100, %[q0]\n\t"
-        "v_mov_b32 v101, %[q1]\n\t"
-        "v_mov_b32 v102, %[q2]\n\t"
-        "v_mov_b32 v103, %[q3]\n\t"
-        "s_waitcnt lgkmcnt(2)\n\t"
-        "v_and_b32 v133, 0xffff, v114\n\t"
-        "v_lshl_add_u32 v112, v133, 4, v139\n\t"
-        "ds_read_b128 v[104:107], v112\n\t"
-        "ds_write_b32 v138, v114\n\t"                     // harmless rewrite: keeps "one op after the reads" for the counted wait
-        "1:\n\t"
-        // ==== step t (p v[104:107], rq v[100:103] -> v[140:143]) ===========================
-        "s_waitcnt lgkmcnt(1)\n\t"
-        "v_pk_mul_f32 v[120:121], v[104:105], v[100:101]\n\t"
-        "v_pk_fma_f32 v[120:121], v[106:107], v[102:103], v[120:121]\n\t"
-        "v_and_b32 v133, 0xffff, v115\n\t"
-        "v_add_f32 v132, v120, v121\n\t"
-        "v_lshl_add_u32 v113, v133, 4, v139\n\t"
-        "v_pk_mul_f32 v[122:123], v[116:117], v[100:101] op_sel:[1,0]\n\t"
-        "v_add_f32_dpp v132, v132, v132 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "ds_read_b128 v[108:111], v113\n\t"
-        "v_pk_mul_f32 v[124:125], v[116:117], v[102:103] op_sel:[1,0]\n\t"
-        "v_add_f32_dpp v132, v132, v132 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "ds_read_b32 v114, v138 offset:%c[e2]\n\t"
-        "ds_read_b64 v[118:119], v138 offset:%c[e1p8]\n\t"
-        "v_add_f32_dpp v132, v132, v132 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp v132, v132, v132 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fma_f32 v130, -%[lr], v132, v116\n\t"
-        "v_pk_fma_f32 v[140:141], v[130:131], v[104:105], v[122:123] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 v[142:143], v[130:131], v[106:107], v[124:125] op_sel_hi:[0,1,1]\n\t"
-        "s_sub_u32 %[n], %[n], 1\n\t"
-        "s_mov_b64 exec, %[lead]\n\t"
-        "ds_write_b32 v144, v130\n\t"                     // post s(t)
-        "s_mov_b64 exec, -1\n\t"
-        // ==== step t+1 (p v[108:111], rq v[140:143] -> v[100:103]) ==========================
-        "s_waitcnt lgkmcnt(1)\n\t"
-        "v_pk_mul_f32 v[120:121], v[108:109], v[140:141]\n\t"
-        "v_pk_fma_f32 v[120:121], v[110:111], v[142:143], v[120:121]\n\t"
-        "v_and_b32 v133, 0xffff, v114\n\t"
-        "v_add_f32 v132, v120, v121\n\t"
-        "v_lshl_add_u32 v112, v133, 4, v139\n\t"
-        "v_pk_mul_f32 v[122:123], v[118:119], v[140:141] op_sel:[1,0]\n\t"
-        "v_add_f32_dpp v132, v132, v132 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "ds_read_b128 v[104:107], v112\n\t"
-        "v_pk_mul_f32 v[124:125], v[118:119], v[142:143] op_sel:[1,0]\n\t"
-        "v_add_f32_dpp v132, v132, v132 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "ds_read_b32 v115, v138 offset:%c[e3]\n\t"
-        "ds_read_b64 v[116:117], v138 offset:%c[e2p8]\n\t"
-        "v_add_f32_dpp v132, v132, v132 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp v132, v132, v132 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fma_f32 v130, -%[lr], v132, v118\n\t"
-        "v_pk_fma_f32 v[100:101], v[130:131], v[108:109], v[122:123] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 v[102:103], v[130:131], v[110:111], v[124:125] op_sel_hi:[0,1,1]\n\t"
-        "v_add_u32 v138, %c[e2], v138\n\t"
-        "s_cmp_lg_u32 %[n], 0\n\t"
-        "s_mov_b64 exec, %[lead]\n\t"
-        "ds_write_b32 v144, v130 offset:16\n\t"           // post s(t+1)
-        "s_mov_b64 exec, -1\n\t"
-        "v_add_u32 v144, 32, v144\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        : [n] "+s"(pairs)
-        : [q0] "v"(q[0]), [q1] "v"(q[1]), [q2] "v"(q[2]), [q3] "v"(q[3]), [ea] "v"(ea), [rb] "v"(rowbase), [mb] "v"(mb),
-          [lr] "s"(lr), [lead] "s"(lead), [e1] "n"(EST), [e2] "n"(2 * EST), [e3] "n"(3 * EST), [e1p8] "n"(EST + 8),
-          [e2p8] "n"(2 * EST + 8)
-        : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110",
-          "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
-          "v124", "v125", "v130", "v131", "v132", "v133", "v138", "v139", "v140", "v141", "v142", "v143", "v144");
-}
-
-// Returns false if the mailbox stayed empty for too long (the caller raises the abort word).
-template <int EST>
-__device__ __forceinline__ bool run_loop_helper_asm(float4& rq, const unsigned ea, const unsigned rowbase,
-                                                    const unsigned mb, int pairs) {
-    using f4 = __attribute__((ext_vector_type(4))) float;
-    f4 q = {rq.x, rq.y, rq.z, rq.w};
-    unsigned spins = 1u << 24;  // polls left (each at least an LDS round trip)
-    asm volatile(
-        "v_mov_b32 v138, %[ea]\n\t"
-        "v_mov_b32 v139, %[rb]\n\t"
-        "v_mov_b32 v144, %[mb]\n\t"
-        "v_mov_b32 v145, -1\n\t"
-        "ds_read_b32 v114, v138\n\t"                      // slots(0)
-        "ds_read_b32 v117, v138 offset:12\n\t"            // ce(0)
-        "ds_read_b32 v115, v138 offset:%c[e1]\n\t"        // slots(1)
-        "v_mov_b32 v100, %[q0]\n\t"
-        "v_mov_b32 v101, %[q1]\n\t"
-        "v_mov_b32 v102, %[q2]\n\t"
-        "v_mov_b32 v103, %[q3]\n\t"
-        // The chain wave may still be in the general steps of this sub-cell, which write p rows the
-        // run reads: no p row is touched before s(0) has been posted (the run has begun).
-        "6:\n\t"
-        "ds_read_b32 v130, v144\n\t"                      // s(0)?
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_eq_u32 vcc, -1, v130\n\t"
-        "s_cbranch_vccz 7f\n\t"
-        "s_sub_u32 %[sp], %[sp], 1\n\t"
-        "s_cmp_eq_u32 %[sp], 0\n\t"
-        "s_cbranch_scc1 9f\n\t"
-        "s_sleep 1\n\t"
-        "s_branch 6b\n\t"
-        "7:\n\t"
-        "v_and_b32 v133, 0xffff, v114\n\t"
-        "v_lshl_add_u32 v112, v133, 4, v139\n\t"
-        "ds_read_b128 v[104:107], v112\n\t"               // p(0)
-        "1:\n\t"
-        // ==== step t: p v[104:107], ce v117, s v130 ==========================================
-        "2:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_eq_u32 vcc, -1, v130\n\t"
-        "s_cbranch_vccz 3f\n\t"
-        "s_sub_u32 %[sp], %[sp], 1\n\t"
-        "s_cmp_eq_u32 %[sp], 0\n\t"
-        "s_cbranch_scc1 9f\n\t"
-        "s_sleep 1\n\t"
-        "ds_read_b32 v130, v144\n\t"
-        "s_branch 2b\n\t"
-        "3:\n\t"
-        "v_and_b32 v133, 0xffff, v115\n\t"
-        "v_lshl_add_u32 v113, v133, 4, v139\n\t"
-        "ds_read_b128 v[108:111], v113\n\t"               // p(t+1)
-        "ds_read_b32 v114, v138 offset:%c[e2]\n\t"        // slots(t+2)
-        "ds_read_b32 v119, v138 offset:%c[e1p12]\n\t"     // ce(t+1)
-        "ds_read_b32 v146, v144 offset:16\n\t"            // s(t+1)? (read ahead)
-        "v_pk_mul_f32 v[126:127], v[116:117], v[104:105] op_sel:[1,0]\n\t"   // ce*p
-        "v_pk_mul_f32 v[128:129], v[116:117], v[106:107] op_sel:[1,0]\n\t"
-        "v_pk_mul_f32 v[122:123], v[116:117], v[100:101] op_sel:[1,0]\n\t"   // ce*rq
-        "v_pk_mul_f32 v[124:125], v[116:117], v[102:103] op_sel:[1,0]\n\t"
-        "v_pk_fma_f32 v[134:135], v[130:131], v[100:101], v[126:127] op_sel_hi:[0,1,1]\n\t"   // p' = s*rq + ce*p
-        "v_pk_fma_f32 v[136:137], v[130:131], v[102:103], v[128:129] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 v[100:101], v[130:131], v[104:105], v[122:123] op_sel_hi:[0,1,1]\n\t"   // rq' = s*p + ce*rq
-        "v_pk_fma_f32 v[102:103], v[130:131], v[106:107], v[124:125] op_sel_hi:[0,1,1]\n\t"
-        "s_nop 0\n\t"
-        "ds_write_b128 v112, v[134:137]\n\t"
-        "ds_write_b32 v144, v145\n\t"                     // mailbox word of step t: empty again
-        // ==== step t+1: p v[108:111], ce v119, s v146 ========================================
-        "4:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_eq_u32 vcc, -1, v146\n\t"
-        "s_cbranch_vccz 5f\n\t"
-        "s_sub_u32 %[sp], %[sp], 1\n\t"
-        "s_cmp_eq_u32 %[sp], 0\n\t"
-        "s_cbranch_scc1 9f\n\t"
-        "s_sleep 1\n\t"
-        "ds_read_b32 v146, v144 offset:16\n\t"
-        "s_branch 4b\n\t"
-        "5:\n\t"
-        "v_and_b32 v133, 0xffff, v114\n\t"
-        "v_lshl_add_u32 v112, v133, 4, v139\n\t"
-        "ds_read_b128 v[104:107], v112\n\t"               // p(t+2)
-        "ds_read_b32 v115, v138 offset:%c[e3]\n\t"        // slots(t+3)
-        "ds_read_b32 v117, v138 offset:%c[e2p12]\n\t"     // ce(t+2)
-        "ds_read_b32 v130, v144 offset:32\n\t"            // s(t+2)? (read ahead)
-        "v_pk_mul_f32 v[126:127], v[118:119], v[108:109] op_sel:[1,0]\n\t"
-        "v_pk_mul_f32 v[128:129], v[118:119], v[110:111] op_sel:[1,0]\n\t"
-        "v_pk_mul_f32 v[122:123], v[118:119], v[100:101] op_sel:[1,0]\n\t"
-        "v_pk_mul_f32 v[124:125], v[118:119], v[102:103] op_sel:[1,0]\n\t"
-        "v_pk_fma_f32 v[134:135], v[146:147], v[100:101], v[126:127] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 v[136:137], v[146:147], v[102:103], v[128:129] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 v[100:101], v[146:147], v[108:109], v[122:123] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 v[102:103], v[146:147], v[110:111], v[124:125] op_sel_hi:[0,1,1]\n\t"
-        "s_nop 0\n\t"
-        "ds_write_b128 v113, v[134:137]\n\t"
-        "ds_write_b32 v144, v145 offset:16\n\t"
-        "v_add_u32 v138, %c[e2], v138\n\t"
-        "v_add_u32 v144, 32, v144\n\t"
-        "s_sub_u32 %[n], %[n], 1\n\t"
-        "s_cmp_lg_u32 %[n], 0\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "9:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mov_b32 %[q0], v100\n\t"
-        "v_mov_b32 %[q1], v101\n\t"
-        "v_mov_b32 %[q2], v102\n\t"
-        "v_mov_b32 %[q3], v103\n\t"
-        : [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [n] "+s"(pairs), [sp] "+s"(spins)
-        : [ea] "v"(ea), [rb] "v"(rowbase), [mb] "v"(mb), [e1] "n"(EST), [e2] "n"(2 * EST), [e3] "n"(3 * EST),
-          [e1p12] "n"(EST + 12), [e2p12] "n"(2 * EST + 12)
-        : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110",
-          "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125",
-          "v126", "v127", "v128", "v129", "v130", "v131", "v133", "v134", "v135", "v136", "v137", "v138", "v139",
-          "v144", "v145", "v146", "v147");
-    rq = make_float4(q[0], q[1], q[2], q[3]);
-    return spins != 0u;
-}
-
 // A chunk descriptor through the scalar path: the index is the same in every lane (it comes from
 // workgroup-uniform counters and from descriptors loaded this way), which the compiler cannot see
 // once it has been through memory -- pin it to an SGPR so that the load is an s_load and the
@@ -434,9 +221,10 @@ __device__ __forceinline__ CellDesc load_desc(const CellDesc* __restrict__ cells
 // Two schedule buffers: the persistent kernel fetches the next cell's schedule (LDS-DMA)
 // while the current cell is being worked on.
 //
-// NH helper waves (0, or W in the persistent training kernel for the geometry whose run loop has
-// the two-wave form): waves W .. W+NH-1.  They take part in staging, gathers and scatters like
-// any other wave; in apply() helper h follows chain wave h through its split runs.
+// NH copy waves (0, or W in the persistent training kernel): waves W .. W+NH-1.  They take part
+// in staging, gathers and scatters like any other wave -- an LDS-DMA gather or a scatter is bound by
+// how fast a wave can issue (~150 cycles per LDS-DMA instruction), so more waves shorten those
+// phases -- and only keep the barriers company in apply(), whose W waves own the sub-cells.
 template <int L, int W, int NH = 0>
 struct Cell {
     static constexpr int G = 64 / L;
@@ -449,10 +237,7 @@ struct Cell {
 
     int tid, lane, wave, g, lig;
     int wave_all;      // index among all NWV waves (copy loops); `wave` is the sub-cell owner index
-    bool helper;       // this wave is a helper (NH > 0 only)
-    unsigned mbox = 0; // LDS byte address of this wave pair's split-run mailbox + 4 * lane slot
-    int split_steps = 0;
-    unsigned* abort_flag = nullptr;  // global abort word (helper spin bound)
+    bool helper;       // this wave is a copy wave (NH > 0 only)
     unsigned laneoff;
     int nu, nrows, n_steps;
     bool critical;  // the cell carries a long per-row chain (scheduler flag)
@@ -609,33 +394,10 @@ struct Cell {
                                           unsigned long long* timers = nullptr) {
         unsigned char* const lr_ = lrows;
         const unsigned lo = laneoff;
-        // a run goes through the two-wave form when the scheduler flagged it and this kernel has helpers
-        auto split_run = [&](const uint2 sd) {
-            const int nr_ = (int)(sd.y >> 16);
-            return NH > 0 && TRAIN && L == 16 && (sd.x & kSubSplit) != 0u && nr_ > 0 && (nr_ & 1) == 0 &&
-                   nr_ <= split_steps;
-        };
         if constexpr (NH > 0) {
-            if (helper) {
-                for (int s = 0; s < W; ++s) {
-                    const uint2 sd = lsub[s * W + wave];
-                    if (split_run(sd)) {
-                        const int n_ = (int)(sd.y & 0xFFFFu), nr_ = (int)(sd.y >> 16);
-                        const uint4* eptr =
-                            lent + (size_t)__builtin_amdgcn_readfirstlane((int)(sd.x & ~kSubSplit)) * G + g + (size_t)n_ * G;
-                        const unsigned ea = (unsigned)(uintptr_t)(lptr_t)eptr;
-                        const unsigned rowbase = (unsigned)(uintptr_t)(lptr_t)lr_ + lo;
-                        const unsigned rqa = (__builtin_amdgcn_ubfe(eptr->x, 16, 15) << 4) + lo;
-                        float4 hq = lds_ld(lr_, rqa);
-                        if (!run_loop_helper_asm<G * 16>(hq, ea, rowbase, mbox, nr_ >> 1)) {
-                            if (lane == 0 && abort_flag)
-                                __hip_atomic_store((__attribute__((address_space(1))) unsigned*)abort_flag, 1u,
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        lds_st(lr_, rqa, hq);  // the helper's copy of the resident rows is the one written back
-                    }
-                    if constexpr (TRAIN) wg_barrier();
-                }
+            if (helper) {  // copy waves: nothing to apply, one barrier per sub-round like everybody else
+                if constexpr (TRAIN)
+                    for (int s = 0; s < W; ++s) wg_barrier();
                 return;
             }
         }
@@ -709,7 +471,7 @@ struct Cell {
             const int nr = nall >> 16;    // run steps, stored after the general ones
             // entries of this wave's sub-cell; the host pads every cell with two idle
             // steps, so reading entries t+1 and t+2 past the end stays inside the image
-            const uint4* ebase = lent + (size_t)__builtin_amdgcn_readfirstlane((int)(sd.x & ~kSubSplit)) * G + g;
+            const uint4* ebase = lent + (size_t)__builtin_amdgcn_readfirstlane((int)sd.x) * G + g;
             unsigned long long tm0 = 0, tm1 = 0, tm2 = 0;
             if constexpr (TIMED) tm0 = __builtin_amdgcn_s_memtime();
             if (n > 0) {
@@ -728,16 +490,7 @@ struct Cell {
                 if (t < n) step(A, B, eptr, 2 * G);
             }
             if constexpr (TIMED) tm1 = __builtin_amdgcn_s_memtime();
-            if (split_run(sd)) {
-                // two-wave form: this wave keeps the dependent chain, its helper does the p rows and
-                // writes the resident rows back
-                const uint4* eptr = ebase + (size_t)n * G;
-                const unsigned ea = (unsigned)(uintptr_t)(lptr_t)eptr;
-                const unsigned rowbase = (unsigned)(uintptr_t)(lptr_t)lr_ + lo;
-                const unsigned rqa = (__builtin_amdgcn_ubfe(eptr->x, 16, 15) << 4) + lo;
-                rq = lds_ld(lr_, rqa);
-                run_loop_chain_asm<G * 16>(rq, ea, rowbase, mbox, nr >> 1, lr);
-            } else if (TRAIN && L == 16 && nr > 0 && (nr & 1) == 0) {
+            if (TRAIN && L == 16 && nr > 0 && (nr & 1) == 0) {
                 // hand-scheduled form of the loop below (k in 33..64: four lane groups of 16)
                 const uint4* eptr = ebase + (size_t)n * G;
                 const unsigned ea = (unsigned)(uintptr_t)(lptr_t)eptr;
@@ -882,22 +635,12 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
                                          const int B, const int n_rounds, const float lr, const float c,
                                          unsigned* __restrict__ done, unsigned* __restrict__ abort_word,
                                          const int sched_cap, const int wg, const int NP,
-                                         unsigned long long* __restrict__ prof, const int split_off,
-                                         const int split_steps) {
+                                         unsigned long long* __restrict__ prof) {
     using gu32 = __attribute__((address_space(1))) unsigned;
     volatile unsigned* const ctl = reinterpret_cast<volatile unsigned*>(smem);  // [0] = abort broadcast
     Cell<L, W, NH> cx;
     cx.init_thread();
     if (cx.tid == 0) ctl[0] = 0;
-    if constexpr (NH > 0) {
-        // split-run mailboxes: (split_steps + 2) x 16 bytes per wave pair, all words "empty"
-        cx.split_steps = split_steps;
-        cx.abort_flag = abort_word;
-        cx.mbox = (unsigned)(uintptr_t)(lptr_t)(smem + split_off) + (unsigned)(cx.wave * (split_steps + 2) * 16 + cx.g * 4);
-        uint32_t* mail = reinterpret_cast<uint32_t*>(smem + split_off);
-        if (split_steps > 0)
-            for (int x = cx.tid; x < W * (split_steps + 2) * 4; x += Cell<L, W, NH>::NT) mail[x] = kMailEmpty;
-    }
 
     // This workgroup's work list: (round R, block b) for b = blockIdx.x, +NP, ... in round order,
     // and within a cell its chunks in chain order.
@@ -1022,11 +765,11 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         for (int k = 0; k < 7; ++k) prof[(size_t)wg * 8 + k] = pacc[k];
 }
 
-// helper waves of the persistent training kernel: one per chain wave where the run loop has the
-// two-wave form (L == 16), none elsewhere
+// copy waves of the persistent training kernel: as many again as apply waves, up to 8 waves in all
+// (16 waves would leave each only 128 VGPRs; the assembly run loop uses v100..v143)
 template <int L, int W>
 constexpr int epoch_helpers() {
-    return (L == 16 && W <= 4) ? W : 0;  // 16 waves would leave each only 128 VGPRs; the run loops use v100..v147
+    return W <= 4 ? W : 0;
 }
 
 template <int L, int W>
@@ -1035,10 +778,10 @@ epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __res
              const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs,
              const Entry* __restrict__ entries, const int B, const int n_rounds, const float lr,
              const float c, unsigned* __restrict__ done, unsigned* __restrict__ abort_word,
-             const int sched_cap, unsigned long long* __restrict__ prof, const int split_off, const int split_steps) {
+             const int sched_cap, unsigned long long* __restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     run_ring<L, W, epoch_helpers<L, W>()>(smem, P, Q, cells, rows, subs, entries, B, n_rounds, lr, c, done, abort_word,
-                                           sched_cap, (int)blockIdx.x, (int)gridDim.x, prof, split_off, split_steps);
+                                           sched_cap, (int)blockIdx.x, (int)gridDim.x, prof);
 }
 
 // Sum of squared errors, persistent form: gridDim.x workgroups walk the B*B cells with a stride,
@@ -1170,8 +913,7 @@ hipError_t epoch_LW(int what, const CellLaunch& a, int n_rounds, unsigned* done,
     }
     hipLaunchKernelGGL((epoch_kernel<L, W>), dim3((unsigned)a.grid), dim3(threads), (size_t)a.lds_bytes, st, a.P, a.Q,
                        a.cells, a.rows, a.subs, a.entries, a.B, n_rounds, a.lr, a.c, done, abort_word, a.sched_cap,
-                       reinterpret_cast<unsigned long long*>(a.diag ? a.sse_partial : nullptr), a.split_off,
-                       a.split_steps);
+                       reinterpret_cast<unsigned long long*>(a.diag ? a.sse_partial : nullptr));
     return hipGetLastError();
 }
 

@@ -21,8 +21,6 @@ struct CellLaunch {
     int grid;        // workgroups: B for a training round, B*B for an SSE pass
     int lds_bytes;   // dynamic LDS per workgroup
     int sched_cap;   // bytes of one of its two schedule buffers
-    int split_off;   // LDS offset of the split-run mailboxes (persistent training kernel)
-    int split_steps; // longest run the scheduler flagged for the two-wave form (0: none)
     float lr;
     float c;         // 1 - lr*lambda
     double* sse_partial;

@@ -79,7 +79,7 @@ struct CellOut {
     std::vector<Entry> entries;
     std::vector<SubDesc> subs;
     std::vector<int64_t> order;
-    uint32_t nu = 0, ni = 0, n_steps = 0, split_steps = 0;
+    uint32_t nu = 0, ni = 0, n_steps = 0;
     int64_t crit = 0;
     bool has_run = false;
 };
@@ -402,9 +402,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     const int64_t ncell = (int64_t)B * B;
     const int WW = W * W;
     const Hyper hy{prm.lr, 1.0f - prm.lr * prm.lambda};
-    // geometries whose run loop has the two-wave form (kernels.hip) keep LDS aside for its mailbox
-    const bool split_ok = geo.L == 16;
-    const int64_t avail = (int64_t)prm.lds_budget - 16 - (split_ok ? (int64_t)W * (kSplitCap + 2) * 16 : 0);
+    const int64_t avail = (int64_t)prm.lds_budget - 16;
     const int64_t min_sched = sched_bytes_for(geo, W, 2, 3), min_rows = rows_bytes_for(geo, 2);
     if (avail < 2 * min_sched + min_rows) {
         err = "lds: the LDS budget cannot hold a single rating at this k";
@@ -505,19 +503,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 }
                 if (ns > 0xFFFF || nr > 0xFFFF) return false;
                 if (nr > 0) o.has_run = true;
-                uint32_t split = 0;
-                if (split_ok && nr > 0 && nr <= (uint32_t)kSplitCap) {
-                    // a helper wave may lag behind the chain wave only if no p-side row comes twice
-                    std::vector<int32_t>& ps = sc.cand;
-                    ps.clear();
-                    for (int j = ngen; j < nsub; ++j) ps.push_back((int32_t)sub[j].p);
-                    std::sort(ps.begin(), ps.end());
-                    if (std::adjacent_find(ps.begin(), ps.end()) == ps.end()) {
-                        split = kSubSplit;
-                        o.split_steps = std::max(o.split_steps, nr);
-                    }
-                }
-                o.subs[(size_t)(s * W + w)] = SubDesc{stepcur | split, ns | (nr << 16)};
+                o.subs[(size_t)(s * W + w)] = SubDesc{stepcur, ns | (nr << 16)};
                 stepcur += ns + nr;
                 smax = std::max(smax, ns + nr);
             }
@@ -750,7 +736,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     out.subs.assign((size_t)(n_descs * WW) + 2, SubDesc{0, 0});  // +16 B: the staging DMA reads whole 16-byte units
     std::vector<const CellOut*> by_desc((size_t)n_descs, nullptr);
     int64_t tot_rows = 0, tot_steps = 0;
-    int64_t sched_cap = 0, rows_cap = 0, split_steps = 0;
+    int64_t sched_cap = 0, rows_cap = 0;
     {
         int64_t next_desc = ncell;
         auto place = [&](int64_t d, const CellOut& o, uint32_t next) -> bool {
@@ -768,7 +754,6 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 out.subs[(size_t)(d * WW + x)] = o.subs.empty() ? SubDesc{0, 0} : o.subs[(size_t)x];
             tot_rows += (int64_t)o.rows.size();
             tot_steps += o.n_steps;
-            split_steps = std::max<int64_t>(split_steps, o.split_steps);
             if (o.n_steps != 0) {
                 sched_cap = std::max(sched_cap, sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps));
                 rows_cap = std::max(rows_cap, rows_bytes_for(geo, (int)(o.nu + o.ni)));
@@ -801,10 +786,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     {
         sched_cap = std::max(sched_cap, min_sched);
         rows_cap = std::max(rows_cap, min_rows);
-        const int64_t split_off = 16 + 2 * sched_cap + rows_cap;
-        const int64_t need = split_off + (split_steps ? (int64_t)W * (split_steps + 2) * 16 : 0);  // +2: read-ahead slots
-        out.split_off = (int)split_off;
-        out.split_steps = (int)split_steps;
+        const int64_t need = 16 + 2 * sched_cap + rows_cap;
         if (need > prm.lds_budget) {
             err = "build_schedule: internal error, chunks need " + std::to_string(need) + " bytes of LDS (budget " +
                   std::to_string(prm.lds_budget) + ")";

@@ -64,13 +64,9 @@ static_assert(sizeof(CellDesc) == 32, "CellDesc layout");
 constexpr uint32_t kCellCritical = 0x80000000u;
 
 struct SubDesc {
-    uint32_t off;  // first step, relative to the cell's first step; bit 31: the run of this sub-cell may
-                   // be split between a chain wave and a helper wave (no user appears twice in it and it
-                   // is at most kSplitCap steps long)
+    uint32_t off;  // first step, relative to the cell's first step
     uint32_t n;    // general steps | run steps << 16 (run steps follow the general ones)
 };
-constexpr uint32_t kSubSplit = 0x80000000u;
-constexpr int kSplitCap = 256;  // longest run handed to a helper wave (its s values sit in LDS: 16 B per step)
 
 struct Entry {
     // p-side LDS address | q-side LDS address << 16 | flag << 31; addresses in 16-byte
@@ -147,10 +143,8 @@ struct Schedule {
     Geometry geo{};
     int B = 0, W = 0;
     int64_t nnz = 0;
-    int lds_bytes = 0;   // 16 + 2 * sched_cap + largest rows image + split-run mailbox
+    int lds_bytes = 0;   // 16 + 2 * sched_cap + largest rows image
     int sched_cap = 0;   // bytes of one schedule buffer (largest cell, multiple of 16)
-    int split_off = 0;   // LDS offset of the split-run mailbox (behind the rows image), split_steps x 16 B per wave
-    int split_steps = 0; // longest run flagged kSubSplit (0: none)
     std::vector<CellDesc> cells;    // chunk descriptors: [0, B*B) first chunks (index ub*B + it), then the rest
     PodVec<uint32_t> rows;          // per chunk: nu user rows then ni item rows
     std::vector<SubDesc> subs;      // (desc*W + s)*W + w

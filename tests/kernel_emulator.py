@@ -50,9 +50,7 @@ def _replay_chunk(oracle, P, Q, k, lr, lam, sched, cell, W, G, L):
                 touched = {}
                 for w in range(W):
                     off, n = (int(v) for v in subs[cell * W * W + s * W + w])
-                    split, off = off >> 31, off & 0x7FFFFFFF  # bit 31: run may be split between two waves
                     ng, nr = n & 0xFFFF, n >> 16
-                    run_users = []
                     # ---- general steps --------------------------------------------------
                     if ng > 0:
                         cur = []
@@ -115,15 +113,12 @@ def _replay_chunk(oracle, P, Q, k, lr, lam, sched, cell, W, G, L):
                                 oracle.sgd_update(p2, rq[g], r, lr, lam)
                                 lds[pa] = p2
                                 real_rows.append(pa)
-                                run_users.append(pa)
                                 for row in (pa, qa):
                                     assert touched.setdefault(row, w) == w, "row shared by two waves in a sub-round"
                             assert len(real_rows) == len(set(real_rows))
                             curp = nxtp
                         for g in range(G):
                             lds[rqa[g]] = rq[g]
-                        if split:  # the helper wave writes p rows late: none may be read twice in the run
-                            assert len(run_users) == len(set(run_users)) and nr <= 256
             assert not lds[nrows:].any(), "an idle slot dirtied the all-zero rows"
             P[ids[:nu]] = lds[:nu]
             Q[ids[nu:]] = lds[nu:nrows]
