@@ -106,7 +106,8 @@ __device__ __forceinline__ void lds_st(unsigned char* base, unsigned off, const 
 // `pairs` x 2 run steps of one wave: resident q rows in v[100:103] / v[140:143] (alternating),
 // one p row prefetched a step ahead, entry words fetched one / two steps ahead.  Per step:
 // 3 dot ops, 4 DPP adds whose two required wait states are filled with the independent
-// scale / address / LDS-issue instructions, 1 fma for s, 4 pk_fma, 1 store.  Arithmetic is
+// scale / address / LDS-issue instructions (the address is one v_mad_u32_u16: low 16 bits of
+// the entry word x 16 + row base), 1 fma for s, 4 pk_fma, 1 store.  Arithmetic is
 // instruction for instruction what Cell::apply's run_step does in C++ (which remains the
 // reference for it and the RMSE path).  Fixed VGPRs v100..v143 are declared clobbered.
 //   ea      : LDS byte address of this lane group's entry of run step 0 (entry stride `EST`)
@@ -137,9 +138,8 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
         "s_waitcnt lgkmcnt(1)\n\t"
         "v_pk_mul_f32 v[120:121], v[104:105], v[100:101]\n\t"
         "v_pk_fma_f32 v[120:121], v[106:107], v[102:103], v[120:121]\n\t"
-        "v_and_b32 v133, 0xffff, v115\n\t"
         "v_add_f32 v132, v120, v121\n\t"
-        "v_lshl_add_u32 v113, v133, 4, v139\n\t"                                  // B.pa
+        "v_mad_u32_u16 v113, v115, 16, v139\n\t"                                  // B.pa = (slots & 0xffff) * 16 + row base
         "v_pk_mul_f32 v[122:123], v[116:117], v[100:101] op_sel:[1,0]\n\t"        // ce*rq01
         "v_add_f32_dpp v132, v132, v132 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "ds_read_b128 v[108:111], v113\n\t"                                       // prefetch p(t+1)
@@ -162,9 +162,8 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
         "s_waitcnt lgkmcnt(1)\n\t"
         "v_pk_mul_f32 v[120:121], v[108:109], v[140:141]\n\t"
         "v_pk_fma_f32 v[120:121], v[110:111], v[142:143], v[120:121]\n\t"
-        "v_and_b32 v133, 0xffff, v114\n\t"
         "v_add_f32 v132, v120, v121\n\t"
-        "v_lshl_add_u32 v112, v133, 4, v139\n\t"                                  // A.pa
+        "v_mad_u32_u16 v112, v114, 16, v139\n\t"                                  // A.pa
         "v_pk_mul_f32 v[122:123], v[118:119], v[140:141] op_sel:[1,0]\n\t"
         "v_add_f32_dpp v132, v132, v132 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "ds_read_b128 v[104:107], v112\n\t"                                       // prefetch p(t+2)
