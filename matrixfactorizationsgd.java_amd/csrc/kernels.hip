@@ -200,6 +200,13 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
     rq = make_float4(q[0], q[1], q[2], q[3]);
 }
 
+// copy waves of the persistent training kernel: as many again as apply waves, up to 8 waves in all
+// (16 waves would leave each only 128 VGPRs; the assembly run loop uses v100..v143)
+template <int L, int W>
+constexpr int epoch_helpers() {
+    return W <= 4 ? W : 0;
+}
+
 // A chunk descriptor through the scalar path: the index is the same in every lane (it comes from
 // workgroup-uniform counters and from descriptors loaded this way), which the compiler cannot see
 // once it has been through memory -- pin it to an SGPR so that the load is an s_load and the
@@ -393,10 +400,9 @@ struct Cell {
                                           unsigned long long* timers = nullptr) {
         unsigned char* const lr_ = lrows;
         const unsigned lo = laneoff;
-        if constexpr (NH > 0) {
+        if constexpr (NH > 0 && TRAIN) {
             if (helper) {  // copy waves: nothing to apply, one barrier per sub-round like everybody else
-                if constexpr (TRAIN)
-                    for (int s = 0; s < W; ++s) wg_barrier();
+                for (int s = 0; s < W; ++s) wg_barrier();
                 return;
             }
         }
@@ -463,8 +469,12 @@ struct Cell {
             }
             nxt.p = pn;
         };
-        for (int s = 0; s < W; ++s) {
-            const uint2 sd = lsub[s * W + wave];
+        // Training: sub-round s, this wave's sub-cell, a barrier after every sub-round.  The RMSE pass
+        // writes nothing, so its sub-cells are independent: every wave of the workgroup (copy waves
+        // included) takes sub-cells wave_all, wave_all + NWV, ... with no barrier in between.
+        const int n_iter = TRAIN ? W : (W * W - wave_all + NWV - 1) / NWV;
+        for (int s = 0; s < n_iter; ++s) {
+            const uint2 sd = lsub[TRAIN ? s * W + wave : wave_all + s * NWV];
             const int nall = __builtin_amdgcn_readfirstlane((int)sd.y);
             const int n = nall & 0xFFFF;  // general steps
             const int nr = nall >> 16;    // run steps, stored after the general ones
@@ -764,13 +774,6 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         for (int k = 0; k < 7; ++k) prof[(size_t)wg * 8 + k] = pacc[k];
 }
 
-// copy waves of the persistent training kernel: as many again as apply waves, up to 8 waves in all
-// (16 waves would leave each only 128 VGPRs; the assembly run loop uses v100..v143)
-template <int L, int W>
-constexpr int epoch_helpers() {
-    return W <= 4 ? W : 0;
-}
-
 template <int L, int W>
 __global__ void __launch_bounds__(64 * (W + epoch_helpers<L, W>()))
 epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __restrict__ cells,
@@ -787,12 +790,13 @@ epoch_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __res
 // the next cell's schedule prefetched (LDS-DMA) while the current one is applied; no writes.
 // One fp64 partial per workgroup (fixed order inside it), reduced by reduce_sse_kernel.
 template <int L, int W>
-__global__ void __launch_bounds__(64 * W)
+__global__ void __launch_bounds__(64 * (W + epoch_helpers<L, W>()))
 sse_kernel(const float* __restrict__ P, const float* __restrict__ Q, const CellDesc* __restrict__ cells,
            const uint32_t* __restrict__ rows, const SubDesc* __restrict__ subs, const Entry* __restrict__ entries,
            const int n_cells, double* __restrict__ sse_partial, const int sched_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Cell<L, W> cx;
+    Cell<L, W, epoch_helpers<L, W>()> cx;
+    constexpr int NWV = W + epoch_helpers<L, W>();
     cx.init_thread();
     const int stride = (int)gridDim.x;
     int c = (int)blockIdx.x;
@@ -829,11 +833,11 @@ sse_kernel(const float* __restrict__ P, const float* __restrict__ Q, const CellD
     for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
     double* wsum = reinterpret_cast<double*>(smem + 16);
     __syncthreads();
-    if (cx.lane == 0) wsum[cx.wave] = v;
+    if (cx.lane == 0) wsum[cx.wave_all] = v;
     __syncthreads();
     if (cx.tid == 0) {
         double t = 0.0;
-        for (int w = 0; w < W; ++w) t += wsum[w];
+        for (int w = 0; w < NWV; ++w) t += wsum[w];
         sse_partial[blockIdx.x] = t;
     }
 }
@@ -973,7 +977,7 @@ hipError_t sse_LW(const CellLaunch& a, int n_cells, hipStream_t st) {
     const void* fn = (const void*)sse_kernel<L, W>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sse_kernel<L, W>), dim3((unsigned)a.grid), dim3(64 * W), (size_t)a.lds_bytes, st, a.P, a.Q, a.cells,
+    hipLaunchKernelGGL((sse_kernel<L, W>), dim3((unsigned)a.grid), dim3(64 * (W + epoch_helpers<L, W>())), (size_t)a.lds_bytes, st, a.P, a.Q, a.cells,
                        a.rows, a.subs, a.entries, n_cells, a.sse_partial, a.sched_cap);
     return hipGetLastError();
 }
