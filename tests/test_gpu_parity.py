@@ -195,13 +195,26 @@ def test_empty_ratings(mf):
         assert np.isfinite(P).all() and np.isfinite(Q).all()
 
 
-def test_hot_item_chain_run_mode(mf, oracle):
+@pytest.mark.parametrize("k", [64, 128, 256])  # 16, 32 and 64 lanes per rating: the three assembly run loops
+def test_hot_item_chain_run_mode(mf, oracle, k):
     rng = np.random.default_rng(9)
     U, I = 3000, 60
     u = list(range(U)) + list(rng.integers(0, U, 6000))
     i = [7] * U + list(rng.integers(0, I, 6000))
     key = np.unique(np.array(u) * I + np.array(i))
-    _run(mf, oracle, U, I, 64, key // I, key % I, rng.random(key.size) * 4 + 1, epochs=2)
+    _, info = _run(mf, oracle, U, I, k, key // I, key % I, rng.random(key.size) * 4 + 1, epochs=2)
+    assert info["waves"] == 2  # one item rated by everybody: chain-bound, two apply waves
+
+
+@pytest.mark.parametrize("k,W", [(128, 4), (256, 4), (128, 1), (96, 2), (200, 8)])
+def test_run_loops_every_wave_count(mf, oracle, k, W):
+    """Skewed items so that runs form, explicit wave counts (copy waves exist for W <= 4 only)."""
+    rng = np.random.default_rng(k + W)
+    U, I, n = 4000, 500, 60000
+    wgt = 1.0 / (np.arange(I) + 1.5)
+    key = np.unique(rng.integers(0, U, n).astype(np.int64) * I + rng.choice(I, n, p=wgt / wgt.sum()))
+    _, info = _run(mf, oracle, U, I, k, key // I, key % I, rng.random(key.size) * 4 + 1, epochs=2, waves=W)
+    assert info["waves"] == W
 
 
 def test_hot_user_chain_swapped_roles(mf, oracle):
