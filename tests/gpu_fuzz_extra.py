@@ -1,0 +1,31 @@
+"""One-off stress beyond the test suite: 400 small random problems and 80 chunk-heavy ones, two
+epochs each on the GPU, factors compared bit for bit with the oracle replaying the exported order.
+
+    python tests/gpu_fuzz_extra.py         # prints "done, mismatches: 0"
+
+Uses the oracle, so it lives under tests/ (not collected by pytest; run it by hand on a GPU box)."""
+import sys, numpy as np
+sys.path.insert(0, '/root/repo')
+import mfsgd_amd as mf
+from tests.oracle_bind import Oracle
+from tests.dsgd_common import fuzz_cases, fuzz_chunked_cases
+orc = Oracle()
+bad = 0
+def check(c, tag, n):
+    global bad
+    u, i, r = c["u"], c["i"], c["r"]
+    with mf.MatrixFactorizationSGD(c["U"], c["I"], c["k"], c["lr"], c["lam"], 5, blocks=c["blocks"], waves=c["waves"]) as m:
+        m.train(u, i, r, 2, rmse=False)
+        P, Q = m.get_factors()
+        order, _ = m.order()
+    Po, Qo = orc.init_factors(c["U"], c["I"], c["k"], 5)
+    for _ in range(2):
+        orc.sgd_pass_ordered(Po, Qo, u, i, r, order, c["lr"], c["lam"])
+    if not (np.array_equal(P, Po) and np.array_equal(Q, Qo)):
+        bad += 1
+        print("MISMATCH", tag, n, c["U"], c["I"], c["k"], len(u), c["blocks"], c["waves"], flush=True)
+for n, c in enumerate(fuzz_cases(400, seed=31337)):
+    check(c, "small", n)
+for n, c in enumerate(fuzz_chunked_cases(80, seed=777, max_ratings=20000)):
+    check(c, "chunked", n)
+print("done, mismatches:", bad)
