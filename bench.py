@@ -147,6 +147,9 @@ def main():
     if rank == 0:
         log(f"generated {w['nnz']} ratings ({w['U']} x {w['I']}, {w['dist']}) in {time.time() - t0:.1f} s")
     k, nnz = w["k"], w["nnz"]
+    # the longest chain of dependent updates on one row: what a sequentially consistent epoch cannot go below
+    max_item_degree = int(np.bincount(w["i"], minlength=w["I"]).max())
+    max_user_degree = int(np.bincount(w["u"], minlength=w["U"]).max())
     flags = (_lib.FLAG_NO_GRAPH if args.no_graph else 0) | (_lib.FLAG_ROUND_LAUNCH if args.round_launch else 0)
 
     # partitions of one rank share its users, so they are trained one after another; more than
@@ -226,7 +229,12 @@ def main():
     units_per_launch = nnz * args.steps / max(1, launches)  # per rank
     achieved_gbs = units_per_launch * bytes_per_update / avg_launch_s / 1e9  # per GPU
     roofline = {
+        # "hbm" is the roofline this path is priced against (gather + axpy, 0.74 flop/B).  `achieved` is
+        # ALGORITHMIC bytes / time, a throughput yardstick: what actually limits a skewed epoch is the longest
+        # chain of dependent updates on one row (`limiter`), and the bytes really moved are `traffic`.
         "bound": "hbm",
+        "limiter": "dependency chain of the heaviest row (%d sequential updates; sum_round_steps %d)"
+                   % (max(max_item_degree, max_user_degree), sum(i["sum_round_steps"] for i in infos)),
         "kernel": ("mfsgd::cell_kernel<L,W,train> (one launch per round)" if args.round_launch
                    else "mfsgd::epoch_kernel<L,W> (persistent: one launch per epoch and item partition)"),
         "achieved": achieved_gbs,
@@ -256,6 +264,8 @@ def main():
             "workload": f"{args.workload} (MovieLens-20M shape, Zipf-Mandelbrot degrees)" if args.workload == "cfg2_ml20m" else args.workload,
             "users_per_gpu": w["U"], "items": w["I"], "nnz_per_gpu": nnz, "k": k,
             "lr": LR, "lambda": LAM, "scale": args.scale,
+            "max_item_degree": max_item_degree, "max_user_degree": max_user_degree,
+            "sum_round_steps": sum(i["sum_round_steps"] for i in infos),
             "blocks": infos[0]["blocks"], "waves": infos[0]["waves"],
             "parts_per_rank": ppr, "emulated_world": emu,
             "parallelism": "single" if world == 1 else f"dsgd{world}" + ("-gloo-rehearsal" if args.backend == "gloo" else ""),

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MFSGD_ABI_VERSION 1
+#define MFSGD_ABI_VERSION 2
 
 typedef enum mfsgd_status {
     MFSGD_OK = 0,
@@ -209,7 +209,22 @@ int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgro
 int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint64_t* out);
 
 /* ---- DSGD building blocks (n_parts > 1) ------------------------------------
- * Item i belongs to partition i % n_parts and is row i / n_parts of that
+ * The global partitioner (host, no GPU): ONE rating set over n_users x n_items is cut for
+ * n_parts devices -- users into n_parts contiguous ranges balanced by rating count (device g
+ * holds the P rows of users [user_begin[g], user_begin[g+1]) and those users' ratings), items
+ * into n_parts partitions balanced by rating count (longest-processing-time-first; items nobody
+ * rated are dealt out to even the row counts).  A pure function of the two degree arrays, so
+ * every rank computes the same plan from the same degrees (a rank that only sees its own ratings
+ * all-reduces the item histogram first).  user_begin: n_parts + 1 entries; item_part: n_items.  */
+int mfsgd_dsgd_plan(const int64_t* deg_user, const int64_t* deg_item, int32_t n_users, int32_t n_items,
+                    int32_t n_parts, int32_t* user_begin, int32_t* item_part);
+/* Installs an item -> partition map (n_items entries in [0, n_parts)) on a handle with
+ * n_parts > 1, before mfsgd_set_ratings; item i is then row (number of smaller item ids in the
+ * same partition) of that partition's Q block.  NULL restores the default below.            */
+int mfsgd_set_item_partition(mfsgd_handle* h, const int32_t* item_part);
+/* The map in force: partition and block row of every item (either pointer may be NULL). */
+int mfsgd_get_item_partition(const mfsgd_handle* h, int32_t* item_part, int32_t* item_row);
+/* Default map: item i belongs to partition i % n_parts and is row i / n_parts of that
  * partition's Q block.  A Q block is a caller-owned DEVICE buffer of
  * mfsgd_part_rows() x kp floats (kp from schedule_info), so that the host side
  * can move it between GPUs (RCCL send/recv) without this library knowing.

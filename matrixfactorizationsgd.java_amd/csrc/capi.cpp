@@ -52,8 +52,9 @@ struct Part {
     DevBuf d_cells, d_rows, d_subs, d_entries, d_sse_partial, d_sse_out;
     DevBuf d_sync;        // persistent kernel: done[B] words (kDoneStride apart) + the abort word
     int persistent_np = -1;  // co-resident workgroups of the epoch kernel; 0 = use round launches; -1 = not probed
-    // training graphs keyed by the Q block pointer they were captured with
-    std::map<const void*, hipGraphExec_t> graphs;
+    // training graphs keyed by the (P, Q) pointers they were captured with (both are baked into the
+    // kernel node; P changes when the factors are re-seeded, Q with every caller-owned block)
+    std::map<std::pair<const void*, const void*>, hipGraphExec_t> graphs;
 };
 
 }  // namespace
@@ -65,6 +66,10 @@ struct mfsgd_handle {
     std::vector<Part> parts;
     bool have_ratings = false;
     int64_t nnz_total = 0;
+    // DSGD item map (n_parts > 1): item i lives in partition item_part[i], row item_row[i] of that
+    // partition's Q block.  Default: i % n_parts, i / n_parts; mfsgd_set_item_partition replaces it.
+    std::vector<int32_t> item_part, item_row, part_q_rows;
+    bool custom_item_map = false;
 
     // factors: host staging (kp-padded rows) until the device copy is created
     enum class Where { None, Host, Device } where = Where::None;
@@ -154,6 +159,33 @@ void drop_graphs(Part& p) {
     for (auto& kv : p.graphs)
         if (kv.second) (void)hipGraphExecDestroy(kv.second);
     p.graphs.clear();
+}
+
+// The device copies of the factors go away (re-seed, set_factors, load): nothing captured with the
+// old pointers may be replayed, and nothing may still be running on them.
+void release_device_factors(mfsgd_handle* h) {
+    if (h->where != mfsgd_handle::Where::Device) return;
+    if (h->device_ready) {
+        (void)hipSetDevice(h->cfg.device);
+        (void)hipDeviceSynchronize();
+    }
+    for (Part& p : h->parts) drop_graphs(p);
+    h->dP.release();
+    h->dQ.release();
+}
+
+void default_item_map(mfsgd_handle* h) {
+    const int G = h->n_parts;
+    const int32_t I = h->cfg.n_items;
+    h->item_part.resize((size_t)I);
+    h->item_row.resize((size_t)I);
+    h->part_q_rows.assign((size_t)G, 0);
+    for (int32_t x = 0; x < I; ++x) {
+        h->item_part[(size_t)x] = x % G;
+        h->item_row[(size_t)x] = x / G;
+    }
+    for (int g = 0; g < G; ++g) h->part_q_rows[(size_t)g] = (I - g + G - 1) / G;
+    h->custom_item_map = false;
 }
 
 size_t sync_bytes(const Part& p) { return ((size_t)p.sched.B * kDoneStride + 4) * sizeof(unsigned); }
@@ -253,7 +285,8 @@ int launch_epoch(mfsgd_handle* h, Part& p, float* Q, hipStream_t st) {
     int rc = probe_persistent(h, p);
     if (rc) return rc;
     if (h->cfg.flags & MFSGD_FLAG_NO_GRAPH) return launch_epoch_body(h, p, Q, st);
-    auto it = p.graphs.find(Q);
+    const auto key = std::make_pair((const void*)h->dP.p, (const void*)Q);
+    auto it = p.graphs.find(key);
     if (it == p.graphs.end()) {
         // capture the launch(es) of one epoch once; replayed every epoch
         hipGraph_t graph = nullptr;
@@ -269,8 +302,12 @@ int launch_epoch(mfsgd_handle* h, Part& p, float* Q, hipStream_t st) {
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         HIPCHK(h, e);
-        if (p.graphs.size() >= 8) drop_graphs(p);
-        it = p.graphs.emplace(Q, exec).first;
+        if (p.graphs.size() >= 32) {
+            // replays of the old graphs may still be in flight on a caller's stream
+            HIPCHK(h, hipDeviceSynchronize());
+            drop_graphs(p);
+        }
+        it = p.graphs.emplace(key, exec).first;
     }
     HIPCHK(h, hipGraphLaunch(it->second, st));
     return MFSGD_OK;
@@ -380,6 +417,12 @@ int mfsgd_create(const mfsgd_config* cfg, mfsgd_handle** out) {
     if (h->n_parts > cfg->n_items) {
         delete h;
         return bad("n_parts exceeds n_items");
+    }
+    try {
+        if (h->n_parts > 1) default_item_map(h);
+    } catch (const std::bad_alloc&) {
+        delete h;
+        return bad("out of host memory", MFSGD_ERR_OOM);
     }
     *out = h;
     return MFSGD_OK;
@@ -505,29 +548,33 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
             }
             if (rc != 0) return fail(h, MFSGD_ERR_SCHEDULE, err);
         } else {
-            // item i -> partition i % G, local row i / G
-            std::vector<int64_t> cnt((size_t)G, 0);
-            for (int64_t j = 0; j < nnz; ++j) cnt[(size_t)(i[j] % G)]++;
+            // item i -> partition item_part[i], local row item_row[i]: one counting sort of the rating
+            // indices by partition, then one schedule per partition
+            std::vector<int64_t> pptr((size_t)G + 1, 0);
+            for (int64_t j = 0; j < nnz; ++j) pptr[(size_t)h->item_part[(size_t)i[j]] + 1]++;
+            for (int g = 0; g < G; ++g) pptr[(size_t)g + 1] += pptr[(size_t)g];
+            std::vector<int64_t> orig((size_t)nnz);
+            {
+                std::vector<int64_t> cur(pptr.begin(), pptr.end() - 1);
+                for (int64_t j = 0; j < nnz; ++j) orig[(size_t)cur[(size_t)h->item_part[(size_t)i[j]]]++] = j;
+            }
+            lap("partition split");
             for (int g = 0; g < G; ++g) {
-                std::vector<int32_t> uu, ii;
-                std::vector<float> rr;
-                std::vector<int64_t> orig;
-                uu.reserve((size_t)cnt[(size_t)g]);
-                ii.reserve((size_t)cnt[(size_t)g]);
-                rr.reserve((size_t)cnt[(size_t)g]);
-                orig.reserve((size_t)cnt[(size_t)g]);
-                for (int64_t j = 0; j < nnz; ++j)
-                    if (i[j] % G == g) {
-                        uu.push_back(u[j]);
-                        ii.push_back(i[j] / G);
-                        rr.push_back(r[j]);
-                        orig.push_back(j);
-                    }
+                const int64_t lo = pptr[(size_t)g], m = pptr[(size_t)g + 1] - lo;
+                std::vector<int32_t> uu((size_t)m), ii((size_t)m);
+                std::vector<float> rr((size_t)m);
+                for (int64_t x = 0; x < m; ++x) {
+                    const int64_t j = orig[(size_t)(lo + x)];
+                    uu[(size_t)x] = u[j];
+                    ii[(size_t)x] = h->item_row[(size_t)i[j]];
+                    rr[(size_t)x] = r[j];
+                }
                 Part& p = h->parts[(size_t)g];
-                p.q_rows = (h->cfg.n_items - g + G - 1) / G;
-                prm.I = p.q_rows;
+                p.q_rows = h->part_q_rows[(size_t)g];
+                prm.I = std::max<int32_t>(1, p.q_rows);
+                prm.validated = true;  // checked above; local rows are in range by construction
                 std::string err;
-                if (build_schedule_auto(prm, uu.data(), ii.data(), rr.data(), orig.data(), (int64_t)uu.size(), p.sched, err) != 0)
+                if (build_schedule_auto(prm, uu.data(), ii.data(), rr.data(), orig.data() + lo, m, p.sched, err) != 0)
                     return fail(h, MFSGD_ERR_SCHEDULE, "partition " + std::to_string(g) + ": " + err);
             }
         }
@@ -547,10 +594,7 @@ int mfsgd_init_p_offset(mfsgd_handle* h, int64_t seed, int64_t u_offset) {
     try {
         const int k = h->cfg.k, kp = h->geo.kp;
         const float scale = (float)(1.0 / std::sqrt((double)k));
-        if (h->where == mfsgd_handle::Where::Device) {
-            h->dP.release();
-            h->dQ.release();
-        }
+        release_device_factors(h);
         h->hP.assign((size_t)h->cfg.n_users * kp, 0.0f);
         JRandom g(seed);
         g.skip((uint64_t)u_offset * (uint64_t)k);
@@ -586,10 +630,7 @@ int mfsgd_set_factors(mfsgd_handle* h, const float* P, const float* Q) {
     if (h->n_parts == 1 && !Q) return fail(h, MFSGD_ERR_INVALID_ARG, "set_factors: Q is null");
     try {
         const int k = h->cfg.k, kp = h->geo.kp;
-        if (h->where == mfsgd_handle::Where::Device) {
-            h->dP.release();
-            h->dQ.release();
-        }
+        release_device_factors(h);
         h->hP.assign((size_t)h->cfg.n_users * kp, 0.0f);
         for (int64_t x = 0; x < h->cfg.n_users; ++x) std::memcpy(&h->hP[(size_t)x * kp], P + x * k, sizeof(float) * (size_t)k);
         h->hQ.clear();
@@ -904,26 +945,80 @@ int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint6
     return MFSGD_OK;
 }
 
+int mfsgd_dsgd_plan(const int64_t* deg_user, const int64_t* deg_item, int32_t n_users, int32_t n_items, int32_t n_parts,
+                    int32_t* user_begin, int32_t* item_part) {
+    if (!deg_user || !deg_item || !user_begin || !item_part || n_users < 1 || n_items < 1 || n_parts < 1)
+        return MFSGD_ERR_INVALID_ARG;
+    for (int32_t x = 0; x < n_users; ++x)
+        if (deg_user[x] < 0) return MFSGD_ERR_INVALID_ARG;
+    for (int32_t x = 0; x < n_items; ++x)
+        if (deg_item[x] < 0) return MFSGD_ERR_INVALID_ARG;
+    try {
+        dsgd_plan(deg_user, deg_item, n_users, n_items, n_parts, user_begin, item_part);
+    } catch (const std::bad_alloc&) {
+        return MFSGD_ERR_OOM;
+    }
+    return MFSGD_OK;
+}
+
+int mfsgd_set_item_partition(mfsgd_handle* h, const int32_t* item_part) {
+    if (!h) return MFSGD_ERR_INVALID_ARG;
+    if (h->n_parts <= 1) return fail(h, MFSGD_ERR_STATE, "set_item_partition: handle has a single partition");
+    if (h->have_ratings) return fail(h, MFSGD_ERR_STATE, "set_item_partition: call it before mfsgd_set_ratings");
+    try {
+        if (!item_part) {
+            default_item_map(h);
+            return MFSGD_OK;
+        }
+        const int G = h->n_parts;
+        const int32_t I = h->cfg.n_items;
+        for (int32_t x = 0; x < I; ++x)
+            if (item_part[x] < 0 || item_part[x] >= G)
+                return fail(h, MFSGD_ERR_INVALID_ARG, "set_item_partition: item " + std::to_string(x) + " has partition " +
+                                                          std::to_string(item_part[x]) + " out of range");
+        h->item_part.assign(item_part, item_part + I);
+        h->item_row.assign((size_t)I, 0);
+        h->part_q_rows.assign((size_t)G, 0);
+        for (int32_t x = 0; x < I; ++x) h->item_row[(size_t)x] = h->part_q_rows[(size_t)item_part[x]]++;
+        h->custom_item_map = true;
+        return MFSGD_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(h, MFSGD_ERR_OOM, "set_item_partition: out of host memory");
+    }
+}
+
+int mfsgd_get_item_partition(const mfsgd_handle* h, int32_t* item_part, int32_t* item_row) {
+    if (!h) return MFSGD_ERR_INVALID_ARG;
+    if (h->n_parts <= 1) return fail(h, MFSGD_ERR_STATE, "get_item_partition: handle has a single partition");
+    if (item_part) std::memcpy(item_part, h->item_part.data(), h->item_part.size() * sizeof(int32_t));
+    if (item_row) std::memcpy(item_row, h->item_row.data(), h->item_row.size() * sizeof(int32_t));
+    return MFSGD_OK;
+}
+
 int mfsgd_part_rows(const mfsgd_handle* h, int32_t part, int32_t* rows) {
     if (!h || !rows) return fail(h, MFSGD_ERR_INVALID_ARG, "part_rows: null argument");
     if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_rows: bad partition");
-    *rows = (h->cfg.n_items - part + h->n_parts - 1) / h->n_parts;
+    *rows = h->n_parts > 1 ? h->part_q_rows[(size_t)part] : h->cfg.n_items;
     return MFSGD_OK;
 }
 
 int mfsgd_part_init_q(const mfsgd_handle* h, int32_t part, int64_t seed, int64_t u_total, float* q_block_host) {
     if (!h || !q_block_host || u_total < 0) return fail(h, MFSGD_ERR_INVALID_ARG, "part_init_q: bad argument");
     if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_init_q: bad partition");
-    const int k = h->cfg.k, kp = h->geo.kp, G = h->n_parts;
+    const int k = h->cfg.k, kp = h->geo.kp;
     const float scale = (float)(1.0 / std::sqrt((double)k));
-    const int32_t rows = (h->cfg.n_items - part + G - 1) / G;
+    // items of this partition in ascending id order = ascending row order; the stream position of
+    // item i is (u_total + i) * k
     JRandom g(seed);
-    g.skip(((uint64_t)u_total + (uint64_t)part) * (uint64_t)k);
-    for (int32_t x = 0; x < rows; ++x) {
-        float* row = q_block_host + (size_t)x * kp;
+    int64_t pos = 0;  // floats drawn so far
+    for (int32_t x = 0; x < h->cfg.n_items; ++x) {
+        if (h->n_parts > 1 && h->item_part[(size_t)x] != part) continue;
+        const int64_t want = ((int64_t)u_total + x) * k;
+        g.skip((uint64_t)(want - pos));
+        float* row = q_block_host + (size_t)(h->n_parts > 1 ? h->item_row[(size_t)x] : x) * kp;
         for (int f = 0; f < k; ++f) row[f] = g.nextFloat() * scale;
         for (int f = k; f < kp; ++f) row[f] = 0.0f;
-        g.skip((uint64_t)(G - 1) * (uint64_t)k);  // next item of this partition is G rows further
+        pos = want + k;
     }
     return MFSGD_OK;
 }

@@ -91,8 +91,14 @@ bool parse_triples(char* p, char sep, bool allow_header, std::vector<int64_t>& u
         char* q = p;
         char* end = nullptr;
         errno = 0;
-        const long long a = std::strtoll(q, &end, 10);
-        if (end == q) {
+        // strtoll skips leading white space, newlines included: a field that is empty up to the end
+        // of its line must not be filled from the next one
+        auto at_eol = [&](const char* x) {
+            while (x < eol && (*x == ' ' || *x == '\t') && *x != sep) ++x;
+            return x >= eol;
+        };
+        const long long a = at_eol(q) ? 0 : std::strtoll(q, &end, 10);
+        if (at_eol(q) || end == q || end > eol) {
             if (allow_header && lineno == 1) {  // "userId,movieId,rating,timestamp"
                 p = next;
                 continue;
@@ -119,8 +125,8 @@ bool parse_triples(char* p, char sep, bool allow_header, std::vector<int64_t>& u
             err = "line " + std::to_string(lineno) + ": missing separator after the user id";
             return false;
         }
-        const long long b = std::strtoll(q, &end, 10);
-        if (end == q) {
+        const long long b = at_eol(q) ? 0 : std::strtoll(q, &end, 10);
+        if (at_eol(q) || end == q || end > eol) {
             err = "line " + std::to_string(lineno) + ": expected an item id";
             return false;
         }

@@ -950,4 +950,48 @@ int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, con
     }
 }
 
+void dsgd_plan(const int64_t* degu, const int64_t* degi, int32_t U, int32_t I, int32_t G, int32_t* user_begin,
+               int32_t* item_part) {
+    // users: boundary g is the first user at which the running rating count reaches g/G of the
+    // total, pushed right where needed so that no range is empty while users remain
+    int64_t total = 0;
+    for (int32_t x = 0; x < U; ++x) total += degu[x];
+    user_begin[0] = 0;
+    {
+        int64_t acc = 0;
+        int32_t x = 0;
+        for (int32_t g = 1; g < G; ++g) {
+            const int64_t want = (int64_t)(((__int128)total * g + G - 1) / G);
+            while (x < U && acc < want) acc += degu[x++];
+            int32_t b = x;
+            if (b <= user_begin[g - 1]) b = std::min<int32_t>(U, user_begin[g - 1] + 1);
+            if (b > U - (G - g)) b = std::max<int32_t>(user_begin[g - 1], U - (G - g));  // leave one user each for the rest
+            while (x < b) acc += degu[x++];
+            user_begin[g] = b;
+        }
+        user_begin[G] = U;
+    }
+    // items: LPT by rating count; unrated items go to the partitions with the fewest rows
+    std::vector<int64_t> deg(degi, degi + I);
+    std::vector<int32_t> bin;
+    lpt_assign(deg, G, bin);
+    std::vector<int64_t> rows((size_t)G, 0);
+    for (int32_t x = 0; x < I; ++x)
+        if (deg[(size_t)x] > 0) rows[(size_t)bin[(size_t)x]]++;
+    using Item = std::pair<int64_t, int32_t>;
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
+    for (int32_t g = 0; g < G; ++g) heap.push({rows[(size_t)g], g});
+    for (int32_t x = 0; x < I; ++x) {
+        if (deg[(size_t)x] > 0) {
+            item_part[x] = bin[(size_t)x];
+            continue;
+        }
+        Item t = heap.top();
+        heap.pop();
+        item_part[x] = t.second;
+        t.first++;
+        heap.push(t);
+    }
+}
+
 }  // namespace mfsgd

@@ -170,4 +170,13 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
 int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, const float* r,
                         const int64_t* orig, int64_t n, Schedule& out, std::string& err);
 
+// DSGD over G devices of ONE global rating set: users are cut into G contiguous
+// ranges balanced by rating count -- device g keeps the P rows of users [user_begin[g],
+// user_begin[g+1]) -- and items into G partitions balanced by rating count (LPT; items nobody
+// rated are dealt out so that the row counts even out).  A pure function of the two degree
+// arrays: every rank computes the same plan from the same (all-reduced) degrees.
+// user_begin: G + 1 entries; item_part: I entries in [0, G).
+void dsgd_plan(const int64_t* degu, const int64_t* degi, int32_t U, int32_t I, int32_t G, int32_t* user_begin,
+               int32_t* item_part);
+
 }  // namespace mfsgd

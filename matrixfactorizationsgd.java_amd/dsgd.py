@@ -117,7 +117,8 @@ class DSGD:
         self.seed, self.u_total, self.nnz_local = seed, u_total, nnz_local
         self.m = int(parts_per_rank)
         self.n_parts = world * self.m
-        self.max_rows = (n_items + self.n_parts - 1) // self.n_parts
+        # every block buffer can hold any partition (a planned item map gives them different row counts)
+        self.max_rows = max(backend.part_rows(p) for p in range(self.n_parts))
         self.kp = kp
         # two buffers of m blocks each: the group being trained and the landing zone of the next
         self.cur = backend.new_block(self.m * self.max_rows, kp)

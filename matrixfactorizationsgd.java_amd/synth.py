@@ -29,8 +29,15 @@ import numpy as np
 WORKLOADS = {
     "cfg0_dense100x80": dict(U=100, I=80, nnz=8000, k=8, dist="dense", seed=1),
     "cfg1_ml100k": dict(U=943, I=1682, nnz=100_000, k=32, dist="uniform", seed=2),
+    # offsets fitted on the GENERATED extremes (de-duplication flattens the head: the expected share of
+    # the heaviest item at q_item = 14 is 0.9 %, what survives is 0.34 %): heaviest item 67,853 ratings
+    # (MovieLens-20M: 67,310), heaviest user 9,215 (9,254), lightest user 11 (20)
     "cfg2_ml20m": dict(U=138_493, I=26_744, nnz=20_000_000, k=64, dist="zm", seed=3,
-                       q_user=370.0, q_item=40.0),
+                       q_user=140.0, q_item=14.0),
+    # SURVEY.md 8d's own proposal, pure Zipf(s = 1) de-duplicated (saturated head; bench / DESIGN only)
+    "cfg2_zipf": dict(U=138_493, I=26_744, nnz=20_000_000, k=64, dist="zm", seed=3, q_user=0.0, q_item=0.0),
+    # the round-1 calibration (heaviest item 40,395 = 0.20 %), kept so that round-1 numbers stay comparable
+    "cfg2_r1": dict(U=138_493, I=26_744, nnz=20_000_000, k=64, dist="zm", seed=3, q_user=370.0, q_item=40.0),
     # same shape as cfg2 with uniform popularity: no long per-row chains (throughput-bound regime)
     "cfg2_uniform": dict(U=138_493, I=26_744, nnz=20_000_000, k=64, dist="uniform", seed=13),
     "cfg3_netflix": dict(U=480_189, I=17_770, nnz=100_000_000, k=128, dist="zm", seed=4,

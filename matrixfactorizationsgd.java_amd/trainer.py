@@ -36,6 +36,19 @@ def _p(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
 
 
+def dsgd_plan(deg_user, deg_item, n_parts):
+    """The global DSGD partitioner (mfsgd_dsgd_plan): (user_begin[n_parts + 1], item_part[n_items])."""
+    du = np.ascontiguousarray(deg_user, np.int64)
+    di = np.ascontiguousarray(deg_item, np.int64)
+    ub = np.empty(int(n_parts) + 1, np.int32)
+    ip = np.empty(di.size, np.int32)
+    rc = _lib.load_library().mfsgd_dsgd_plan(_p(du, C.c_int64), _p(di, C.c_int64), du.size, di.size, int(n_parts),
+                                             _p(ub, C.c_int32), _p(ip, C.c_int32))
+    if rc != 0:
+        raise MfsgdError(rc, "mfsgd_dsgd_plan: bad argument")
+    return ub, ip
+
+
 class MatrixFactorizationSGD:
     def __init__(self, users, items, k, lr, lam, seed, *, device=0, blocks=0, waves=0,
                  n_parts=0, host_threads=0, flags=0):
@@ -227,6 +240,22 @@ class MatrixFactorizationSGD:
         return out[:B * 6].reshape(B, 6)
 
     # -- DSGD building blocks (n_parts > 1); see dsgd.py ---------------------------
+    def set_item_partition(self, item_part):
+        """Item -> partition map (mfsgd_dsgd_plan's), before set_ratings; None = i % n_parts."""
+        if item_part is None:
+            self._check(self._lib.mfsgd_set_item_partition(self._handle(), None))
+            return
+        ip = _i32(item_part)
+        if ip.shape != (self.items,):
+            raise ValueError("item_part must have one entry per item")
+        self._check(self._lib.mfsgd_set_item_partition(self._handle(), _p(ip, C.c_int32)))
+
+    def item_partition(self):
+        part = np.empty(self.items, np.int32)
+        row = np.empty(self.items, np.int32)
+        self._check(self._lib.mfsgd_get_item_partition(self._handle(), _p(part, C.c_int32), _p(row, C.c_int32)))
+        return part, row
+
     def part_rows(self, part):
         rows = C.c_int32()
         self._check(self._lib.mfsgd_part_rows(self._handle(), int(part), C.byref(rows)))

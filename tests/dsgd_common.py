@@ -38,6 +38,57 @@ def sequential_dsgd(oracle, trainers, data, U_local, I, k, G, epochs, parts_per_
     return P, Q, sse
 
 
+# ---- one GLOBAL rating set cut by the product's partitioner (mfsgd_dsgd_plan) -----------------
+def plan_shards(mf, U, I, u, i, G):
+    """(user_begin, item_part, [indices of shard g's ratings])."""
+    ub, ip = mf.dsgd_plan(np.bincount(u, minlength=U), np.bincount(i, minlength=I), G)
+    sel = [np.flatnonzero((u >= ub[g]) & (u < ub[g + 1])) for g in range(G)]
+    return ub, ip, sel
+
+
+def plan_trainer(mf, g, ub, ip, sel, I, k, u, i, r, G, lr=LR, lam=LAM, seed=SEED, **kw):
+    """Handle of device g: its user range, its users' ratings (local user ids, global item ids)."""
+    t = mf.MatrixFactorizationSGD(int(ub[g + 1] - ub[g]), I, k, lr, lam, seed, n_parts=G, **kw)
+    t.set_item_partition(ip)
+    t.set_ratings(u[sel[g]] - ub[g], i[sel[g]], r[sel[g]])
+    t.init_p_offset(seed, int(ub[g]))
+    return t
+
+
+def sequential_dsgd_plan(oracle, trainers, sel, U, I, k, u, i, r, G, epochs, lr=LR, lam=LAM, seed=SEED, mt_threads=0):
+    """The sequential definition for a planned problem: global factors, sub-epoch s, device g
+    trains partition (g+s)%G in the order its handle exports (indices into the shard)."""
+    P, Q = oracle.init_factors(U, I, k, seed)
+    sse = []
+    orders = {}
+    for _ in range(epochs):
+        for s in range(G):
+            for g in range(G):
+                part = (g + s) % G
+                if (g, part) not in orders:
+                    order, cell_ptr = trainers[g].order(part)
+                    info = trainers[g].schedule_info(part)
+                    orders[(g, part)] = (sel[g][order], cell_ptr, info["rounds"], info["blocks"])
+                order, cell_ptr, rounds, blocks = orders[(g, part)]
+                if order.size == 0:
+                    continue
+                if mt_threads > 1:
+                    oracle.sgd_epoch_mt(P, Q, u, i, r, order, cell_ptr, rounds, blocks, lr, lam, mt_threads)
+                else:
+                    oracle.sgd_pass_ordered(P, Q, u, i, r, order, lr, lam)
+        sse.append(oracle.sse(P, Q, u, i, r))
+    return P, Q, sse
+
+
+def assemble_q_plan(blocks, ip, I, k):
+    """Dense I x k matrix from {partition: block}: partition rows are its items in ascending id order."""
+    Q = np.zeros((I, k), np.float32)
+    for part, blk in blocks.items():
+        idx = np.flatnonzero(ip == part)
+        Q[idx] = blk[: idx.size, :k]
+    return Q
+
+
 class OracleBackend:
     """CPU stand-in for dsgd.HipBackend (tests only)."""
 
@@ -45,6 +96,7 @@ class OracleBackend:
         self.torch, self.o, self.t = torch, oracle, trainer
         self.u, self.i, self.r, self.k, self.G = u, i, r, k, G
         self.P, _ = trainer.get_factors()
+        self.item_row = trainer.item_partition()[1]
 
     def new_block(self, rows, kp):
         return self.torch.zeros((rows, kp), dtype=self.torch.float32)
@@ -69,14 +121,14 @@ class OracleBackend:
         order = self._sel(part)
         rows = self.part_rows(part)
         Qb = np.ascontiguousarray(block.numpy()[:rows, : self.k])
-        self.o.sgd_pass_ordered(self.P, Qb, self.u, self.i // self.G, self.r, order, LR, LAM)
+        self.o.sgd_pass_ordered(self.P, Qb, self.u, self.item_row[self.i], self.r, order, LR, LAM)
         block[:rows, : self.k] = self.torch.from_numpy(Qb)
 
     def part_sse(self, part, block):
         order = self._sel(part)
         rows = self.part_rows(part)
         Qb = np.ascontiguousarray(block.numpy()[:rows, : self.k])
-        return self.o.sse(self.P, Qb, self.u[order], (self.i // self.G)[order], self.r[order])
+        return self.o.sse(self.P, Qb, self.u[order], self.item_row[self.i][order], self.r[order])
 
     def synchronize(self):
         pass

@@ -18,9 +18,10 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,m", [(2, 1), (3, 1), (2, 3)])
+@pytest.mark.parametrize("world,m", [(2, 1), (3, 1), (2, 3), (2, 0), (3, 0)])  # m = 0: one global set cut by mfsgd_dsgd_plan
 def test_dsgd_ring_over_gloo(mf, world, m):
-    env = dict(os.environ, OMP_NUM_THREADS="1", MFSGD_TEST_PARTS_PER_RANK=str(m))
+    env = dict(os.environ, OMP_NUM_THREADS="1", MFSGD_TEST_PARTS_PER_RANK=str(max(m, 1)),
+               MFSGD_TEST_PLANNED="1" if m == 0 else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "dsgd_gloo_worker.py")]
