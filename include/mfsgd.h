@@ -69,6 +69,7 @@ typedef struct mfsgd_config {
 #define MFSGD_FLAG_NO_GRAPH 1     /* launch eagerly instead of replaying a hipGraph            */
 #define MFSGD_FLAG_HOST_INGEST 4   /* bucket the ratings on the host even when a GPU is present     */
 #define MFSGD_FLAG_DEVICE_INGEST 8 /* ... on the GPU even for small rating sets (default: >= 2^20)  */
+#define MFSGD_FLAG_NO_SOLO 16      /* schedule without solo runs (A/B measurements, tests)           */
 #define MFSGD_FLAG_ROUND_LAUNCH 2 /* one kernel launch per round instead of the persistent      */
                                   /* epoch kernel (which hands item tiles between workgroups)   */
 
@@ -184,9 +185,12 @@ int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t
  * cells: n_cells x 8 words {row_off, ent_off, n_steps, nu | ni << 16, next chunk, 3 reserved}: chunk
  * descriptors -- the first blocks*blocks are the first chunk of each cell, a cell too large for
  * the LDS continues through `next` (0 = last chunk) into the descriptors behind them;
- * subs: n_subs x 2 words {off, general steps | run steps << 16};
+ * subs: n_subs x 2 words {off | solo steps << 16, general steps | run steps << 16};
  * entries: n_entries x 4 words {p addr | q addr << 16 | flag << 31 (16-byte units), rating bits,
- * bits of lr*rating, bits of the slot's decay factor}.                                         */
+ * bits of lr*rating, bits of the slot's decay factor}.  A sub-cell's solo run follows its run steps
+ * and two idle steps (padded to whole steps): header {0, slots_0, 0, 0}, then per step {bits of lr*rating, slots of the
+ * NEXT step, 0xFFFFFFFF (mailbox), rating bits}, then a terminator; the slots behind the last step
+ * address an all-zero row.                                                                      */
 int mfsgd_debug_schedule_sizes(const mfsgd_handle* h, int32_t part, int64_t* n_cells, int64_t* n_rows,
                                int64_t* n_subs, int64_t* n_entries);
 int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cells, uint32_t* rows,

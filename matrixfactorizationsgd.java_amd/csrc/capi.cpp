@@ -513,6 +513,7 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
         prm.B = h->cfg.blocks;
         prm.W = h->cfg.waves;
         prm.threads = h->cfg.host_threads;
+        prm.solo = !(h->cfg.flags & MFSGD_FLAG_NO_SOLO);
         if (G == 1) {
             Part& p = h->parts[0];
             p.q_rows = h->cfg.n_items;

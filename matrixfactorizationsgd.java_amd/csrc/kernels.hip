@@ -21,6 +21,7 @@
 #include <cstdint>
 
 #include "kernels.hpp"
+#include "solo_asm.hpp"
 
 #pragma clang fp contract(off)
 
@@ -222,6 +223,30 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
     rq = make_float4(q[0], q[1], q[2], q[3]);
 }
 
+// ---- solo run: chain wave / helper wave (solo_asm.hpp) -------------------------------------
+// `ea`: LDS byte address of the run's header record, `rowbase`: LDS byte address of row slot 0 plus
+// this lane's 16-byte offset inside a row, n >= 1 steps, c2 = {c, c} as one 64-bit scalar.
+template <int L>
+__device__ __forceinline__ void solo_chain_asm(const float4 rq, const unsigned ea, const unsigned rowbase, int n,
+                                               const float lr, const uint64_t c2) {
+    static_assert(L == 16 || L == 32 || L == 64, "solo loops: 16, 32 or 64 lanes per rating");
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    const f4 q = {rq.x, rq.y, rq.z, rq.w};
+    if constexpr (L == 16)
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT("") MFSGD_SOLO_CHAIN_OPERANDS);
+    else if constexpr (L == 32)
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_SWAP_ADD16) MFSGD_SOLO_CHAIN_OPERANDS);
+    else
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_SWAP_ADD16 MFSGD_SWAP_ADD32) MFSGD_SOLO_CHAIN_OPERANDS);
+}
+// Returns false if it gave up waiting for the chain wave (bounded polling; cannot happen with a
+// schedule the packer built -- the bound only keeps a corrupt one from hanging the GPU).
+__device__ __forceinline__ bool solo_helper_asm(const unsigned ea, const unsigned rowbase, int n, const uint64_t c2) {
+    int spins = 1 << 22;
+    asm volatile(MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_OPERANDS);
+    return spins != 0;
+}
+
 // copy waves of the persistent training kernel: as many again as apply waves, up to 8 waves in all
 // (16 waves would leave each only 128 VGPRs; the assembly run loop uses v100..v143)
 template <int L, int W>
@@ -269,6 +294,7 @@ struct Cell {
     unsigned laneoff;
     int nu, nrows, n_steps;
     bool critical;  // the cell carries a long per-row chain (scheduler flag)
+    volatile unsigned* fail_flag = nullptr;  // LDS control word a helper raises when it gives up (persistent kernel)
     unsigned char* lrows;
     uint4* lent;
     uint2* lsub;
@@ -423,8 +449,25 @@ struct Cell {
         unsigned char* const lr_ = lrows;
         const unsigned lo = laneoff;
         if constexpr (NH > 0 && TRAIN) {
-            if (helper) {  // copy waves: nothing to apply, one barrier per sub-round like everybody else
-                for (int s = 0; s < W; ++s) wg_barrier();
+            if (helper) {
+                // Copy waves keep the barriers company: one per sub-round like everybody else.  Copy wave h
+                // is also the HELPER of apply wave (h + 1) % W -- a wave on another SIMD -- whenever that
+                // wave's sub-cell ends in a solo run: it follows the chain wave through the run's mailboxes,
+                // redoes the q recurrence and does all the stores (solo_asm.hpp).
+                for (int s = 0; s < W; ++s) {
+                    if constexpr (L >= 16) {
+                        const uint2 sd = lsub[s * W + (wave + 1) % W];
+                        const int ns = __builtin_amdgcn_readfirstlane((int)(sd.x >> 16));
+                        if (ns > 0) {
+                            const int first = __builtin_amdgcn_readfirstlane((int)((sd.x & 0xFFFFu) + (sd.y & 0xFFFFu) + (sd.y >> 16))) + kSoloPad;
+                            const uint4* hdr = lent + (size_t)first * G;
+                            const uint64_t c2 = ((uint64_t)__builtin_bit_cast(unsigned, c) << 32) | __builtin_bit_cast(unsigned, c);
+                            if (!solo_helper_asm((unsigned)(uintptr_t)(lptr_t)hdr, (unsigned)(uintptr_t)(lptr_t)lr_ + lo, ns, c2))
+                                if (fail_flag) *fail_flag = 1;
+                        }
+                    }
+                    wg_barrier();
+                }
                 return;
             }
         }
@@ -499,10 +542,12 @@ struct Cell {
             const uint2 sd = lsub[TRAIN ? s * W + wave : wave_all + s * NWV];
             const int nall = __builtin_amdgcn_readfirstlane((int)sd.y);
             const int n = nall & 0xFFFF;  // general steps
-            const int nr = nall >> 16;    // run steps, stored after the general ones
+            const int nr = (int)((unsigned)nall >> 16);  // run steps, stored after the general ones
+            const int offs = __builtin_amdgcn_readfirstlane((int)sd.x);
+            const int nsolo = (int)((unsigned)offs >> 16);  // solo records, stored after the run steps
             // entries of this wave's sub-cell; the host pads every cell with two idle
             // steps, so reading entries t+1 and t+2 past the end stays inside the image
-            const uint4* ebase = lent + (size_t)__builtin_amdgcn_readfirstlane((int)sd.x) * G + g;
+            const uint4* ebase = lent + (size_t)(offs & 0xFFFF) * G + g;
             unsigned long long tm0 = 0, tm1 = 0, tm2 = 0;
             if constexpr (TIMED) tm0 = __builtin_amdgcn_s_memtime();
             if (n > 0) {
@@ -547,6 +592,47 @@ struct Cell {
                 }
                 if (t < nr) run_step(A, B, eptr, 2 * G);
                 if constexpr (TRAIN) lds_st(lr_, rqa, rq);
+            }
+            if (nsolo > 0) {
+                // Solo run: header record, then one 16-byte record per step {lr*r, next slots, mailbox, r}.
+                const uint4* hdr = lent + (size_t)((offs & 0xFFFF) + n + nr + kSoloPad) * G;
+                const unsigned s0 = hdr->y;
+                const unsigned rqa = (__builtin_amdgcn_ubfe(s0, 16, 15) << 4) + lo;
+                if constexpr (TRAIN && NH > 0 && L >= 16) {
+                    // chain wave: dot -> s -> q' only; its helper (a copy wave) stores the p rows and q
+                    const uint64_t c2 = ((uint64_t)__builtin_bit_cast(unsigned, c) << 32) | __builtin_bit_cast(unsigned, c);
+                    solo_chain_asm<L>(lds_ld(lr_, rqa), (unsigned)(uintptr_t)(lptr_t)hdr, (unsigned)(uintptr_t)(lptr_t)lr_ + lo,
+                                      nsolo, lr, c2);
+                } else if constexpr (TRAIN) {
+                    // one wave does everything (kernels without copy waves); every lane group computes the
+                    // same step -- the chain is sequential -- and they all store the same bits
+                    float4 q = lds_ld(lr_, rqa);
+                    unsigned pa = ((s0 & 0xFFFFu) << 4) + lo;
+                    for (int t = 0; t < nsolo; ++t) {
+                        const uint4 e = hdr[1 + t];
+                        const float4 p = lds_ld(lr_, pa);
+                        const float dot = group_allreduce<L>(chunk_dot(p, q));
+                        const float sc = __builtin_fmaf(-lr, dot, __builtin_bit_cast(float, e.x));
+                        const float4 p2 = axpy_row(sc, q, c, p);
+                        q = axpy_row(sc, p, c, q);
+                        lds_st(lr_, pa, p2);
+                        pa = ((e.y & 0xFFFFu) << 4) + lo;
+                    }
+                    lds_st(lr_, rqa, q);
+                } else {
+                    // RMSE: nothing is written, so lane group g takes steps g, g + G, ... (the address of step
+                    // t sits in record t - 1; groups past the end read the zero row with r = 0)
+                    const float4 q = lds_ld(lr_, rqa);
+                    for (int t0 = 0; t0 < nsolo; t0 += G) {
+                        const int t = t0 + g;
+                        const bool live = t < nsolo;
+                        const uint4 e = hdr[1 + (live ? t : nsolo)];  // past the end: the terminator (r = 0)
+                        const unsigned sl = hdr[live ? t : nsolo].y;    // ... whose predecessor addresses the zero row
+                        const float4 p = lds_ld(lr_, ((sl & 0xFFFFu) << 4) + lo);
+                        const float err = __builtin_bit_cast(float, e.w) - group_allreduce<L>(chunk_dot(p, q));
+                        acc += (double)err * (double)err;
+                    }
+                }
             }
             if constexpr (TIMED) {
                 tm2 = __builtin_amdgcn_s_memtime();
@@ -671,6 +757,7 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     volatile unsigned* const ctl = reinterpret_cast<volatile unsigned*>(smem);  // [0] = abort broadcast
     Cell<L, W, NH> cx;
     cx.init_thread();
+    cx.fail_flag = ctl;
     if (cx.tid == 0) ctl[0] = 0;
 
     // This workgroup's work list: (round R, block b) for b = blockIdx.x, +NP, ... in round order,
@@ -756,7 +843,10 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         mark(1);  // waiting for the tile (wave 0)
         wg_barrier();
         mark(2);  // the other waves' arrival
-        if (ctl[0] != 0) return;  // uniform: some workgroup timed out
+        if (ctl[0] != 0) {  // uniform: some workgroup timed out (or a solo helper of this one gave up)
+            if (cx.tid == 0) __hip_atomic_store((gu32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         const Item it2 = next_item(it1, cd1);
         if (work) cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
         // descriptor used two iterations from now: a scalar load issued here, behind every gather of
@@ -792,6 +882,8 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         it1 = it2;
         mark(6);  // own rows stored (not drained), end barrier
     }
+    if (ctl[0] != 0 && cx.tid == 0)  // raised during the last cell
+        __hip_atomic_store((gu32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prof && cx.tid == 0)
         for (int k = 0; k < 7; ++k) prof[(size_t)wg * 8 + k] = pacc[k];
 }

@@ -97,6 +97,7 @@ struct Scratch {
 };
 
 constexpr int kRunMin = 8;  // shortest item chain worth a register-resident run
+constexpr int kSoloMin = 12;  // shortest chain worth a solo run (a second wave does the off-chain half)
 
 // Packs the ratings rs[0..n) of one sub-cell into steps of G conflict-free
 // slots.  `t0` is the running step stamp of the cell (unique per step).
@@ -306,6 +307,37 @@ void pack_run(const Rat* rs, int n, const uint16_t* run_q, int nrun, int G, int 
     }
 }
 
+// A SOLO run: the ratings of ONE item whose users are all distinct, as a compact stream of 16-byte
+// records (kernels.hip, solo_asm.hpp): [header][record 0] ... [record n-1][terminator], padded to
+// whole steps.  record t = {lr * r_t, slots_{t+1}, mailbox (0xFFFFFFFF), r_t}; header = {0, slots_0,
+// 0, 0}; slots = p-row address | q-row address << 16; the address behind the last step is a zero row.
+// Every step decays with the same factor (no idle slots), so none is stored.
+void pack_solo(const Rat* rs, int n, int G, int Lg, int nrows, const Hyper& hy, std::vector<Entry>& entries,
+               std::vector<int64_t>& order, uint32_t& n_units) {
+    auto words = [](uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+        Entry e;
+        const uint32_t w[4] = {a, b, c, d};
+        std::memcpy(&e, w, sizeof e);
+        return e;
+    };
+    auto bits = [](float f) {
+        uint32_t x;
+        std::memcpy(&x, &f, 4);
+        return x;
+    };
+    const uint32_t q = rs[0].q;
+    const uint32_t zero_slots = encode_slots(nrows, (int)q, false, Lg);
+    auto slots_of = [&](int t) { return t < n ? encode_slots(rs[t].p, (int)q, false, Lg) : zero_slots; };
+    entries.push_back(words(0u, slots_of(0), 0u, 0u));
+    for (int t = 0; t < n; ++t) {
+        entries.push_back(words(bits(hy.lr * rs[t].r), slots_of(t + 1), 0xFFFFFFFFu, bits(rs[t].r)));
+        order.push_back(rs[t].idx);
+    }
+    entries.push_back(words(0u, zero_slots, 0xFFFFFFFFu, 0u));
+    n_units = (uint32_t)((n + 2 + G - 1) / G);
+    for (int x = n + 2; x < (int)n_units * G; ++x) entries.push_back(words(0u, zero_slots, 0xFFFFFFFFu, 0u));
+}
+
 }  // namespace
 
 int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, const float* r,
@@ -402,6 +434,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     const int64_t ncell = (int64_t)B * B;
     const int WW = W * W;
     const Hyper hy{prm.lr, 1.0f - prm.lr * prm.lambda};
+    // solo runs pay where the kernel has the two-wave loops for them: 16+ lanes per rating (k > 32) and
+    // a workgroup with copy waves (W <= 4); elsewhere a solo run would only be a slower run
+    const bool solo_ok = prm.solo && geo.L >= 16 && W <= 4;
     const int64_t avail = (int64_t)prm.lds_budget - 16;
     const int64_t min_sched = sched_bytes_for(geo, W, 2, 3), min_rows = rows_bytes_for(geo, 2);
     if (avail < 2 * min_sched + min_rows) {
@@ -484,7 +519,34 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     top.erase(std::unique(top.begin(), top.end()), top.end());
                     for (size_t x = 0; x < top.size() && nrun < G; ++x) run_q[nrun++] = top[x].second;
                 }
-                int ngen = nsub;
+                // A solo run for the heaviest run item when it dwarfs the others (their run would be
+                // over in a quarter of its steps: taking it out costs less than it saves) and its
+                // users are all distinct (a repeated (user, item) pair has to see its own update).
+                bool solo = false;
+                uint16_t solo_q = 0;
+                if (solo_ok && nrun > 0) {
+                    const int n1 = -sc.top[0].first, n2 = sc.top.size() > 1 ? -sc.top[1].first : 0;
+                    if (n1 >= kSoloMin && 4 * n2 <= n1) {
+                        solo = true;
+                        solo_q = sc.top[0].second;
+                        const int32_t stamp = ++tstamp;
+                        for (int j = 0; j < nsub && solo; ++j)
+                            if (sub[j].q == solo_q) {
+                                if (sc.laststep[sub[j].p] == stamp) solo = false;
+                                sc.laststep[sub[j].p] = stamp;
+                            }
+                    }
+                    if (solo) {
+                        for (int g = 1; g < nrun; ++g) run_q[g - 1] = run_q[g];
+                        --nrun;
+                    }
+                }
+                int ngen = nsub, nsolo = 0;
+                if (solo) {  // solo ratings last
+                    nsolo = nsub - (int)(std::stable_partition(sub, sub + nsub, [&](const Rat& x) { return x.q != solo_q; }) - sub);
+                    ngen = nsub - nsolo;
+                }
+                const int nnon = ngen;  // general + run ratings
                 if (nrun > 0) {
                     // stable partition: general ratings first, run ratings after
                     auto is_run = [&](const Rat& x) {
@@ -492,20 +554,32 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                             if (run_q[g] == x.q) return true;
                         return false;
                     };
-                    ngen = (int)(std::stable_partition(sub, sub + nsub, [&](const Rat& x) { return !is_run(x); }) - sub);
+                    ngen = (int)(std::stable_partition(sub, sub + nnon, [&](const Rat& x) { return !is_run(x); }) - sub);
                 }
                 ++tstamp;  // break stickiness across sub-cells
                 pack_subcell(sub, ngen, G, geo.L, nrows, hy, sc, tstamp, o.entries, o.order, ns);
                 if (nrun > 0) {
                     ++tstamp;  // the run starts with fresh loads: no hazard against the last general step
-                    pack_run(sub + ngen, nsub - ngen, run_q, nrun, G, geo.L, nrows, hy, sc, tstamp, o.entries, o.order,
+                    pack_run(sub + ngen, nnon - ngen, run_q, nrun, G, geo.L, nrows, hy, sc, tstamp, o.entries, o.order,
                              nr);
                 }
-                if (ns > 0xFFFF || nr > 0xFFFF) return false;
-                if (nr > 0) o.has_run = true;
-                o.subs[(size_t)(s * W + w)] = SubDesc{stepcur, ns | (nr << 16)};
-                stepcur += ns + nr;
-                smax = std::max(smax, ns + nr);
+                uint32_t nsu = 0;  // step units the solo records occupy
+                if (nsolo > 0) {
+                    ++tstamp;
+                    // the general and run loops read one and two steps ahead: two idle steps keep that
+                    // look-ahead on step-format entries, whatever follows
+                    for (int pad = 0; pad < kSoloPad; ++pad)
+                        for (int g = 0; g < G; ++g)
+                            o.entries.push_back(make_entry(encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, geo.L), 0.0f, hy.c, hy));
+                    pack_solo(sub + nnon, nsolo, G, geo.L, nrows, hy, o.entries, o.order, nsu);
+                    nsu += kSoloPad;
+                }
+                if (ns > 0xFFFF || nr > 0xFFFF || nsolo > 0xFFFF || stepcur > 0xFFFF) return false;
+                if (nr > 0 || nsolo > 0) o.has_run = true;
+                o.subs[(size_t)(s * W + w)] = SubDesc{stepcur | ((uint32_t)nsolo << 16), ns | (nr << 16)};
+                stepcur += ns + nr + nsu;
+                // a solo step costs about three quarters of a run step (137 against 184 cycles at L = 16)
+                smax = std::max(smax, ns + nr + (uint32_t)(nsolo * 3 / 4));
             }
             crit += smax;
         }

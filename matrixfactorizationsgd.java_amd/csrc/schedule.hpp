@@ -64,9 +64,12 @@ static_assert(sizeof(CellDesc) == 32, "CellDesc layout");
 constexpr uint32_t kCellCritical = 0x80000000u;
 
 struct SubDesc {
-    uint32_t off;  // first step, relative to the cell's first step
-    uint32_t n;    // general steps | run steps << 16 (run steps follow the general ones)
+    uint32_t off;  // first step, relative to the cell's first step (low 16 bits) | solo steps << 16
+    uint32_t n;    // general steps | run steps << 16 (run steps follow the general ones, the solo
+                   // records -- 16 bytes each, header first -- follow kSoloPad idle steps behind them)
 };
+
+constexpr int kSoloPad = 2;  // idle steps between a sub-cell's run steps and its solo records
 
 struct Entry {
     // p-side LDS address | q-side LDS address << 16 | flag << 31; addresses in 16-byte
@@ -137,6 +140,7 @@ struct SchedParams {
     const int64_t* degu = nullptr;
     const int64_t* degi = nullptr;
     bool validated = false;
+    bool solo = true;  // allow solo runs (MFSGD_FLAG_NO_SOLO clears it: A/B measurements, tests)
 };
 
 struct Schedule {

@@ -1,0 +1,174 @@
+// solo_asm.hpp -- hand-scheduled gfx950 loops of a SOLO run: one item's
+// chain of dependent updates, split between the wave that owns the sub-cell (the CHAIN wave:
+// dot -> s -> q', nothing else) and one copy wave of the same workgroup on another SIMD (the
+// HELPER: re-runs the cheap q recurrence from the posted s and does everything that is not on
+// the chain -- p' = fma(s, q, c p), its store, and the final store of q).
+//
+// A solo run of n steps is a compact stream of 16-byte entries in the LDS schedule image:
+//     [header][entry 0] ... [entry n-1][terminator]
+//     entry t   = { lr * r_t,  slots_{t+1},  mailbox_t,  r_t }
+//     header    = { 0,         slots_0,      0,          0   }
+//     slots_t   = p-row LDS address | q-row LDS address << 16 (16-byte units); slots_n (in entry
+//                 n-1 and in the terminator) addresses an all-zero row
+//     mailbox_t = 0xFFFFFFFF in the schedule; the chain wave overwrites it with the bits of s_t,
+//                 which is how the helper learns that step t has happened and what s_t was.
+// The decay factor is the same for every step (there are no idle slots in a solo run), so it is
+// an operand (SGPR pair {c, c}), not part of the entry.  Arithmetic is, instruction for
+// instruction, DESIGN.md section 3: the pair of waves produces the bits Cell::solo_generic does.
+//
+// Shared with tools/ubench3.hip, which times the two loops against each other in isolation.
+#pragma once
+
+// ---- chain wave -------------------------------------------------------------------------------
+// v138 entry pointer (-> entry t at the top of half A), v139 row base + this lane's 16-byte offset;
+// v[100:103] q (updated in place); v[104:107] / v[108:111] p row of the even / odd step (prefetched
+// a step ahead); v[116:117] / v[118:119] {lr*r, next slots} of the even / odd step; v113 p address;
+// v[120:121] chunk products, v132 dot, v[122:125] c*q, v130 s.
+#define MFSGD_SOLO_CHAIN_HALF(P0, P1, P2, P3, N0, N1, N2, N3, ELRR, ESLOT, NEXTE, OFF_NEXT, OFF_MBOX, EXTRA) \
+        "s_waitcnt lgkmcnt(1)\n\t" \
+        "v_pk_mul_f32 v[120:121], v[" P0 ":" P1 "], v[100:101]\n\t" \
+        "v_pk_fma_f32 v[120:121], v[" P2 ":" P3 "], v[102:103], v[120:121]\n\t" \
+        "v_add_f32 v132, v120, v121\n\t" \
+        "v_mad_u32_u16 v113, v" ESLOT ", 16, v139\n\t" \
+        "v_pk_mul_f32 v[122:123], v[100:101], %[c2]\n\t" \
+        "v_add_f32_dpp v132, v132, v132 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "ds_read_b128 v[" N0 ":" N3 "], v113\n\t" \
+        "v_pk_mul_f32 v[124:125], v[102:103], %[c2]\n\t" \
+        "v_add_f32_dpp v132, v132, v132 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "ds_read_b64 v[" NEXTE "], v138 offset:" OFF_NEXT "\n\t" \
+        "s_nop 0\n\t" \
+        "v_add_f32_dpp v132, v132, v132 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "s_nop 1\n\t" \
+        "v_add_f32_dpp v132, v132, v132 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        EXTRA \
+        "v_fma_f32 v130, -%[lr], v132, v" ELRR "\n\t" \
+        "v_pk_fma_f32 v[100:101], v[130:131], v[" P0 ":" P1 "], v[122:123] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 v[102:103], v[130:131], v[" P2 ":" P3 "], v[124:125] op_sel_hi:[0,1,1]\n\t" \
+        "s_sub_u32 %[n], %[n], 1\n\t" \
+        "ds_write_b32 v138, v130 offset:" OFF_MBOX "\n\t" \
+        "s_cmp_eq_u32 %[n], 0\n\t"
+
+// `ea` = LDS byte address of the header entry; n >= 1 steps.
+#define MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA) \
+        "v_mov_b32 v138, %[ea]\n\t" \
+        "v_mov_b32 v139, %[rb]\n\t" \
+        "ds_read_b32 v133, v138 offset:4\n\t" \
+        "ds_read_b64 v[116:117], v138 offset:16\n\t" \
+        "v_mov_b32 v100, %[q0]\n\t" \
+        "v_mov_b32 v101, %[q1]\n\t" \
+        "v_mov_b32 v102, %[q2]\n\t" \
+        "v_mov_b32 v103, %[q3]\n\t" \
+        "s_waitcnt lgkmcnt(1)\n\t" \
+        "v_mad_u32_u16 v113, v133, 16, v139\n\t" \
+        "ds_read_b128 v[104:107], v113\n\t" \
+        "ds_write_b32 v138, v133 offset:4\n\t" \
+        "s_nop 1\n\t" \
+        "v_add_u32 v138, 16, v138\n\t" \
+        "1:\n\t" \
+        MFSGD_SOLO_CHAIN_HALF("104", "105", "106", "107", "108", "109", "110", "111", "116", "117", "118:119", "16", "8", EXTRA) \
+        "s_cbranch_scc1 2f\n\t" \
+        MFSGD_SOLO_CHAIN_HALF("108", "109", "110", "111", "104", "105", "106", "107", "118", "119", "116:117", "32", "24", EXTRA) \
+        "v_add_u32 v138, 32, v138\n\t" \
+        "s_cbranch_scc0 1b\n\t" \
+        "2:\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t"
+
+#define MFSGD_SOLO_CHAIN_OPERANDS                                                                                      \
+    : [n] "+s"(n)                                                                                                      \
+    : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [c2] "s"(c2), [q0] "v"(q[0]), [q1] "v"(q[1]), [q2] "v"(q[2]),     \
+      [q3] "v"(q[3])                                                                                                   \
+    : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
+      "v113", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v130", "v131", "v132",  \
+      "v133", "v138", "v139"
+
+// ---- helper wave ------------------------------------------------------------------------------
+// v138 entry pointer (-> entry t at the top of half A), v139 row base + lane offset; v[100:103] q_t;
+// v[104:107] / v[108:111] p row of the even / odd step; v[116:117] / v[118:119] {mailbox_t = s_t,
+// slots_{t+1}} of the even / odd step; v112 / v113 p address of the even / odd step; v140 q address;
+// v[122:125] c*q, v[126:129] c*p, v[134:137] p'.  %[spins]: polls left before giving up (the chain
+// wave always arrives; the bound only keeps a broken schedule from hanging the GPU) -- on return
+// %[spins] == 0 means it gave up and nothing further was written.
+#ifndef MFSGD_HV
+#define MFSGD_HV 2
+#endif
+// fast path falls through; the re-poll loop of half TAG sits out of line (MFSGD_SOLO_HELPER_SLOW)
+#define MFSGD_SOLO_HELPER_HALF(TAG, P0, P1, P2, P3, N0, N3, MBOX, MSLOT, MPAIR, NEXTM, PADDR, NADDR, OFF0, OFF1) \
+        "s_waitcnt lgkmcnt(1)\n\t" \
+        "v_cmp_eq_u32 vcc, -1, v" MBOX "\n\t" \
+        "v_mad_u32_u16 v" NADDR ", v" MSLOT ", 16, v139\n\t" \
+        "v_pk_mul_f32 v[126:127], v[" P0 ":" P1 "], %[c2]\n\t" \
+        "s_cbranch_vccnz 2" TAG "f\n\t" \
+        "1" TAG ":\n\t" \
+        "ds_read_b128 v[" N0 ":" N3 "], v" NADDR "\n\t" \
+        "v_pk_mul_f32 v[128:129], v[" P2 ":" P3 "], %[c2]\n\t" \
+        "ds_read2_b32 v[" NEXTM "], v138 " OFF0 "\n\t" \
+        "v_pk_mul_f32 v[122:123], v[100:101], %[c2]\n\t" \
+        "v_pk_mul_f32 v[124:125], v[102:103], %[c2]\n\t" \
+        "v_pk_fma_f32 v[134:135], v[" MPAIR "], v[100:101], v[126:127] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 v[136:137], v[" MPAIR "], v[102:103], v[128:129] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 v[100:101], v[" MPAIR "], v[" P0 ":" P1 "], v[122:123] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 v[102:103], v[" MPAIR "], v[" P2 ":" P3 "], v[124:125] op_sel_hi:[0,1,1]\n\t" \
+        "s_sub_u32 %[n], %[n], 1\n\t" \
+        "ds_write_b128 v" PADDR ", v[134:137]\n\t" \
+        "s_cmp_eq_u32 %[n], 0\n\t"
+
+#define MFSGD_SOLO_HELPER_SLOW(TAG, MBOX, OFF1) \
+        "2" TAG ":\n\t" \
+        "s_sleep 1\n\t" \
+        "ds_read_b32 v" MBOX ", v138 offset:" OFF1 "\n\t" \
+        "s_sub_u32 %[spins], %[spins], 1\n\t" \
+        "s_cmp_eq_u32 %[spins], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_cmp_eq_u32 vcc, -1, v" MBOX "\n\t" \
+        "s_cbranch_vccnz 2" TAG "b\n\t" \
+        "s_branch 1" TAG "b\n\t"
+
+#define MFSGD_SOLO_HELPER_ASM_TEXT \
+        "v_mov_b32 v138, %[ea]\n\t" \
+        "v_mov_b32 v139, %[rb]\n\t" \
+        "ds_read_b32 v133, v138 offset:4\n\t" \
+        "ds_read2_b32 v[116:117], v138 offset0:6 offset1:5\n\t" \
+        "s_waitcnt lgkmcnt(1)\n\t" \
+        "v_mad_u32_u16 v112, v133, 16, v139\n\t" \
+        "v_bfe_u32 v140, v133, 16, 15\n\t" \
+        "v_lshl_add_u32 v140, v140, 4, v139\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_cmp_eq_u32 vcc, -1, v116\n\t" \
+        "s_cbranch_vccz 4f\n\t" \
+        "3:\n\t" \
+        "s_sleep 1\n\t" \
+        "ds_read_b32 v116, v138 offset:24\n\t" \
+        "s_sub_u32 %[spins], %[spins], 1\n\t" \
+        "s_cmp_eq_u32 %[spins], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_cmp_eq_u32 vcc, -1, v116\n\t" \
+        "s_cbranch_vccnz 3b\n\t" \
+        "4:\n\t" \
+        "ds_read_b128 v[100:103], v140\n\t" \
+        "ds_read_b128 v[104:107], v112\n\t" \
+        "ds_write_b32 v138, v133 offset:4\n\t" \
+        "s_nop 1\n\t" \
+        "v_add_u32 v138, 16, v138\n\t" \
+        "5:\n\t" \
+        MFSGD_SOLO_HELPER_HALF("0", "104", "105", "106", "107", "108", "111", "116", "117", "116:117", "118:119", "112", "113", "offset0:6 offset1:5", "8") \
+        "s_cbranch_scc1 8f\n\t" \
+        MFSGD_SOLO_HELPER_HALF("1", "108", "109", "110", "111", "104", "107", "118", "119", "118:119", "116:117", "113", "112", "offset0:10 offset1:9", "24") \
+        "v_add_u32 v138, 32, v138\n\t" \
+        "s_cbranch_scc0 5b\n\t" \
+        "8:\n\t" \
+        "s_nop 0\n\t" \
+        "ds_write_b128 v140, v[100:103]\n\t" \
+        "s_branch 9f\n\t" \
+        MFSGD_SOLO_HELPER_SLOW("0", "116", "8") \
+        MFSGD_SOLO_HELPER_SLOW("1", "118", "24") \
+        "9:\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t"
+
+#define MFSGD_SOLO_HELPER_OPERANDS                                                                                     \
+    : [n] "+s"(n), [spins] "+s"(spins)                                                                                 \
+    : [ea] "v"(ea), [rb] "v"(rowbase), [c2] "s"(c2)                                                                    \
+    : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110",  \
+      "v111", "v112", "v113", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",  \
+      "v129", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140"

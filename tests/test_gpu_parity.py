@@ -582,3 +582,32 @@ def test_reinit_after_training(mf, oracle, n_parts):
         Q = assemble_q({p: blocks[p].cpu().numpy() for p in range(n_parts)}, I, k, n_parts)
         del hog
     assert np.array_equal(P, Po) and np.array_equal(Q, Qo)
+
+
+# ---- solo runs: chain wave + helper wave (solo_asm.hpp), and the one-wave forms of the same records ---
+@pytest.mark.parametrize("k,W", [(64, 1), (64, 2), (64, 4), (100, 2), (128, 2), (128, 4), (256, 2), (256, 4)])
+def test_solo_runs_every_geometry(mf, oracle, k, W):
+    from mfsgd_amd import _lib
+
+    rng = np.random.default_rng(k * 10 + W)
+    U, I = 3000, 80
+    u = list(range(U)) + list(rng.integers(0, U, 9000))  # item 7 rated by everybody, odd and even run lengths
+    i = [7] * U + list(rng.integers(0, I, 9000))
+    key = rng.permutation(np.unique(np.array(u) * I + np.array(i)))
+    uu, ii, rr = key // I, key % I, rng.random(key.size) * 4 + 1
+    B = 12 if k == 256 else 5
+    for flags in (0, _lib.FLAG_ROUND_LAUNCH, _lib.FLAG_NO_SOLO):
+        with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 3, blocks=B, waves=W, flags=flags) as m:
+            m.set_ratings(uu, ii, rr)
+            solo = int((m.debug_schedule()[2][:, 0] >> 16).sum())
+        assert (solo == 0) == (flags == _lib.FLAG_NO_SOLO), (flags, solo)
+        _run(mf, oracle, U, I, k, uu, ii, rr, epochs=2, blocks=B, waves=W, flags=flags)
+
+
+def test_solo_runs_on_the_bench_shape(mf, oracle):
+    """cfg2 scaled: the calibrated head makes solo runs in the hot tile; auto geometry."""
+    w = mf.synth.workload("cfg2_ml20m", scale=0.1)
+    with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 3) as m:
+        m.set_ratings(w["u"], w["i"], w["r"])
+        assert int((m.debug_schedule()[2][:, 0] >> 16).sum()) > 0
+    _run(mf, oracle, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"], epochs=2)

@@ -228,3 +228,50 @@ def test_fuzz_chunked_schedules_replay_exactly(mf, oracle):
         np.testing.assert_array_equal(Qe, Q)
         split += info["split_cells"] > 0
     assert split >= 3
+
+
+# ---- solo runs: one item's chain as compact records, stored by a helper wave on the device ------------
+def _solo_steps(m):
+    cells, rows, subs, entries = m.debug_schedule()
+    return int((subs[:, 0] >> 16).sum())
+
+
+def test_solo_runs_form_for_a_dominant_item_and_replay_exactly(mf, oracle):
+    from mfsgd_amd import _lib
+
+    rng = np.random.default_rng(21)
+    U, I = 400, 50
+    u = list(range(U)) + list(rng.integers(0, U, 900))
+    i = [7] * U + list(rng.integers(0, I, 900))
+    key = np.unique(np.array(u) * I + np.array(i))
+    uu, ii, rr = key // I, key % I, rng.random(key.size) * 4 + 1
+    for k, W, B in ((64, 2, 2), (128, 4, 2), (256, 2, 8), (64, 1, 2)):  # k = 256: a cell holds ~140 rows
+        _check(mf, oracle, U, I, k, uu, ii, rr, blocks=B, waves=W)
+        with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 3, blocks=B, waves=W) as m:
+            m.set_ratings(uu, ii, rr)
+            assert _solo_steps(m) >= U // 2, (k, W, "the hot item's ratings should sit in solo runs")
+            order_solo = m.order()[0]
+        with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 3, blocks=B, waves=W, flags=_lib.FLAG_NO_SOLO) as m:
+            m.set_ratings(uu, ii, rr)
+            assert _solo_steps(m) == 0
+            assert sorted(m.order()[0].tolist()) == sorted(order_solo.tolist())
+    # no solo runs where the kernel has no two-wave loops for them: k <= 32 (fewer than 16 lanes), W = 8
+    for k, W in ((32, 2), (64, 8)):
+        with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 3, blocks=2, waves=W) as m:
+            m.set_ratings(uu, ii, rr)
+            assert _solo_steps(m) == 0
+
+
+def test_repeated_pairs_never_go_solo(mf, oracle):
+    # the hot item's ratings include the same (user, item) pair twice: a solo run stores p rows late,
+    # so such a chain must stay an ordinary run
+    U, I = 200, 20
+    u = list(range(U)) + [5, 5, 9]
+    i = [3] * U + [3, 3, 3]
+    r = np.linspace(1, 5, len(u))
+    _check(mf, oracle, U, I, 64, u, i, r, blocks=1, waves=2)
+    with mf.MatrixFactorizationSGD(U, I, 64, LR, LAM, 3, blocks=1, waves=2) as m:
+        m.set_ratings(u, i, r)
+        cells, rows, subs, entries = m.debug_schedule()
+        # user sub-group holding users 5 and 9 has repeats; at most the other sub-group went solo
+        assert int((subs[:, 0] >> 16).sum()) < U

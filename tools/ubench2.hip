@@ -5,6 +5,9 @@
 #ifndef V
 #define V 0
 #endif
+#ifndef XMASK
+#define XMASK 0xffffffffffffffffull
+#endif
 #define DPPI(c) "v_add_f32_dpp v132, v132, v132 " c " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #if V == 1
 #define DPP(c) "s_nop 0\n\t"
@@ -43,6 +46,7 @@ __global__ void k(unsigned long long* cyc, float* out, int iters, float lr) {
     const unsigned lane16 = (threadIdx.x & 15) * 16, ea = 32768 + (threadIdx.x >> 4) * 16;
     float o;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    asm volatile("s_mov_b64 exec, %0\n\ts_nop 4" ::"s"(XMASK));
     asm volatile(
         "v_mov_b32 v138, %[ea]\n\tv_mov_b32 v139, %[rb]\n\tv_mov_b32 v115, 0\n\tv_mov_b32 v112, %[rb]\n\tv_mov_b32 v113, %[rb]\n\t"
         "v_mov_b32 v100, 1.0\n\tv_mov_b32 v101, 1.0\n\tv_mov_b32 v102, 1.0\n\tv_mov_b32 v103, 1.0\n\t"
@@ -108,6 +112,7 @@ __global__ void k(unsigned long long* cyc, float* out, int iters, float lr) {
         : [n] "+s"(n), [o] "=v"(o)
         : [ea] "v"(ea), [rb] "v"(lane16), [lr] "s"(lr), [mask] "s"(0x0001000100010001ull)
         : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v144", "v145", "v146", "v147");
+    asm volatile("s_mov_b64 exec, -1\n\ts_nop 4");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     out[threadIdx.x] = o;
     if (threadIdx.x == 0) cyc[0] = t1 - t0;
@@ -117,6 +122,6 @@ int main() {
     const int iters = 4096; unsigned long long h = 0, best = ~0ull;
     for (int r = 0; r < 5; ++r) { hipLaunchKernelGGL(k, dim3(1), dim3(64), 65536, 0, c, o, iters, 0.01f); hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost); if (h < best) best = h; }
     const char* names[] = {"full step", "DPP adds -> s_nop", "no LDS ops (+4 movs gone)", "no scale pk_mul x4", "no p' update + store", "pure dependent chain", "no address calc", "entry: one b128 read", "entry: one b64 read", "store as 2 x b64", "store as 4 x b32", "store as write2_b64", "chain wave of a two-wave split"};
-    printf("V=%d %-28s %7.1f cycles/step\n", V, names[V], (double)best / iters);
+    printf("V=%d mask=%llx %-28s %7.1f cycles/step\n", V, (unsigned long long)XMASK, names[V], (double)best / iters);
     return 0;
 }

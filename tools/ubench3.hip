@@ -1,0 +1,177 @@
+// Microbenchmark + correctness check of the SOLO run loops (csrc/solo_asm.hpp): one workgroup of
+// two waves on two SIMDs, wave 0 = chain wave, wave 1 = helper.  Prints cycles per step of the pair
+// (and of the chain wave alone, MODE=1: no helper, nothing stored) and compares every p row and the
+// q row with a plain host restatement of DESIGN.md section 3.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../matrixfactorizationsgd.java_amd/csrc/solo_asm.hpp"
+
+#ifndef LG
+#define LG 16  // lanes per rating
+#endif
+#define SWAP16 "v_mov_b32 v133, v132\n\ts_nop 1\n\tv_permlane16_swap_b32 v132, v133\n\ts_nop 1\n\tv_add_f32 v132, v132, v133\n\t"
+#define SWAP32 "v_mov_b32 v133, v132\n\ts_nop 1\n\tv_permlane32_swap_b32 v132, v133\n\ts_nop 1\n\tv_add_f32 v132, v132, v133\n\t"
+#if LG == 16
+#define EXTRA ""
+#elif LG == 32
+#define EXTRA SWAP16
+#else
+#define EXTRA SWAP16 SWAP32
+#endif
+
+constexpr int ROWB = 16 * LG;
+constexpr int NSTEP = (LG == 64 ? 120 : 300), NROWS = NSTEP + 2;  // p rows 0..NSTEP-1, q row NSTEP, zero row NSTEP+1
+constexpr int ENT_OFF = NROWS * ROWB;          // entries behind the rows
+
+__global__ void __launch_bounds__(128) k(const float* rows_in, const uint32_t* ent_in, float* rows_out, uint32_t* ent_out,
+                                         unsigned long long* cyc, int n_steps, float lr, float c, int mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    for (int x = threadIdx.x; x < NROWS * ROWB / 4; x += 128) ((float*)smem)[x] = rows_in[x];
+    for (int x = threadIdx.x; x < (NSTEP + 2) * 4; x += 128) ((uint32_t*)(smem + ENT_OFF))[x] = ent_in[x];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned rowbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem + (lane % LG) * 16;
+    const unsigned ea = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + ENT_OFF);
+    const uint64_t c2 = ((uint64_t)__builtin_bit_cast(uint32_t, c) << 32) | __builtin_bit_cast(uint32_t, c);
+    unsigned long long t0 = 0, t1 = 0;
+    int n = n_steps;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    if (wave == 0 && mode != 2) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 q = *(const f4*)(smem + NSTEP * ROWB + (lane % LG) * 16);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA) MFSGD_SOLO_CHAIN_OPERANDS);
+    } else if (wave == 1 && (mode == 0 || mode == 2)) {
+        int spins = 1 << 20;
+        asm volatile(MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_OPERANDS);
+        if (spins == 0 && lane == 0) cyc[2] = 1;
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    if (lane == 0) cyc[wave] = t1 - t0;
+    __syncthreads();
+    for (int x = threadIdx.x; x < NROWS * ROWB / 4; x += 128) rows_out[x] = ((float*)smem)[x];
+    for (int x = threadIdx.x; x < (NSTEP + 2) * 4; x += 128) ent_out[x] = ((uint32_t*)(smem + ENT_OFF))[x];
+}
+
+static float ref_dot(const float* p, const float* q) {
+    float s[64];
+    for (int c = 0; c < LG; ++c) {
+        float t0 = p[4 * c] * q[4 * c], t1 = p[4 * c + 1] * q[4 * c + 1];
+        t0 = fmaf(p[4 * c + 2], q[4 * c + 2], t0);
+        t1 = fmaf(p[4 * c + 3], q[4 * c + 3], t1);
+        s[c] = t0 + t1;
+    }
+    for (int m = 1; m < LG; m <<= 1) {
+        float t[64];
+        for (int c = 0; c < LG; ++c) t[c] = s[c] + s[c ^ m];
+        memcpy(s, t, sizeof(float) * LG);
+    }
+    return s[0];
+}
+
+int main() {
+    const int KP = 4 * LG;
+    std::vector<float> rows((size_t)NROWS * KP), ref;
+    uint32_t seed = 12345;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)(seed >> 8) / (float)(1 << 24); };
+    for (int r = 0; r <= NSTEP; ++r)
+        for (int f = 0; f < KP; ++f) rows[(size_t)r * KP + f] = rnd() * 0.25f;
+    for (int f = 0; f < KP; ++f) rows[(size_t)(NSTEP + 1) * KP + f] = 0.f;
+    const float lr = 0.01f, c = 1.0f - 0.01f * 0.05f;
+    // steps visit the p rows in a scrambled order
+    std::vector<int> prow(NSTEP);
+    for (int t = 0; t < NSTEP; ++t) prow[t] = (t * 7) % NSTEP;
+    std::vector<float> rr(NSTEP);
+    std::vector<uint32_t> ent((NSTEP + 2) * 4, 0);
+    auto slots = [&](int pr) { return (uint32_t)(pr * LG) | ((uint32_t)(NSTEP * LG) << 16); };
+    ent[1] = slots(prow[0]);
+    for (int t = 0; t < NSTEP; ++t) {
+        rr[t] = 1.0f + 4.0f * rnd();
+        const float lrr = lr * rr[t];
+        memcpy(&ent[(t + 1) * 4 + 0], &lrr, 4);
+        ent[(t + 1) * 4 + 1] = t + 1 < NSTEP ? slots(prow[t + 1]) : slots(NSTEP + 1);
+        ent[(t + 1) * 4 + 2] = 0xFFFFFFFFu;
+        memcpy(&ent[(t + 1) * 4 + 3], &rr[t], 4);
+    }
+    ent[(NSTEP + 1) * 4 + 1] = slots(NSTEP + 1);
+    ent[(NSTEP + 1) * 4 + 2] = 0xFFFFFFFFu;
+    // host restatement
+    ref = rows;
+    float* q = &ref[(size_t)NSTEP * KP];
+    for (int t = 0; t < NSTEP; ++t) {
+        float* p = &ref[(size_t)prow[t] * KP];
+        const float dot = ref_dot(p, q), s = fmaf(-lr, dot, lr * rr[t]);
+        for (int f = 0; f < KP; ++f) {
+            const float po = p[f], qo = q[f];
+            p[f] = fmaf(s, qo, c * po);
+            q[f] = fmaf(s, po, c * qo);
+        }
+    }
+    float *d_in, *d_out;
+    uint32_t *d_ent, *d_ent_out;
+    unsigned long long* d_cyc;
+    (void)hipMalloc(&d_in, rows.size() * 4);
+    (void)hipMalloc(&d_out, rows.size() * 4);
+    (void)hipMalloc(&d_ent, ent.size() * 4);
+    (void)hipMalloc(&d_ent_out, ent.size() * 4);
+    (void)hipMalloc(&d_cyc, 32);
+    (void)hipMemcpy(d_in, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_ent, ent.data(), ent.size() * 4, hipMemcpyHostToDevice);
+    const size_t lds = (size_t)NROWS * ROWB + (NSTEP + 2) * 16;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // mode 2: mailboxes pre-filled with the reference's s_t -> the helper's own pace
+    std::vector<uint32_t> ent2 = ent;
+    {
+        std::vector<float> r2 = rows;
+        float* qq = &r2[(size_t)NSTEP * KP];
+        for (int t = 0; t < NSTEP; ++t) {
+            float* p = &r2[(size_t)prow[t] * KP];
+            const float dot = ref_dot(p, qq), s = fmaf(-lr, dot, lr * rr[t]);
+            memcpy(&ent2[(t + 1) * 4 + 2], &s, 4);
+            for (int f = 0; f < KP; ++f) {
+                const float po = p[f], qo = qq[f];
+                p[f] = fmaf(s, qo, c * po);
+                qq[f] = fmaf(s, po, c * qo);
+            }
+        }
+    }
+    for (int mode = 0; mode < 3; ++mode)
+        for (int n : {NSTEP, NSTEP - 1, 1, 2}) {
+            (void)hipMemcpy(d_ent, (mode == 2 ? ent2 : ent).data(), ent.size() * 4, hipMemcpyHostToDevice);
+            unsigned long long best[2] = {~0ull, ~0ull}, h[4];
+            std::vector<float> out(rows.size());
+            for (int rep = 0; rep < 5; ++rep) {
+                (void)hipMemset(d_cyc, 0, 32);
+                hipLaunchKernelGGL(k, dim3(1), dim3(128), lds, 0, d_in, d_ent, d_out, d_ent_out, d_cyc, n, lr, c, mode);
+                (void)hipMemcpy(h, d_cyc, 32, hipMemcpyDeviceToHost);
+                if (h[2]) printf("helper gave up!\n");
+                for (int w = 0; w < 2; ++w) best[w] = h[w] < best[w] ? h[w] : best[w];
+            }
+            (void)hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost);
+            int bad = 0;
+            if (mode != 1 && n == NSTEP) bad = memcmp(out.data(), ref.data(), out.size() * 4) != 0;
+            if (mode != 1 && n != NSTEP) {  // partial run: recompute the reference for n steps
+                std::vector<float> r2 = rows;
+                float* qq = &r2[(size_t)NSTEP * KP];
+                for (int t = 0; t < n; ++t) {
+                    float* p = &r2[(size_t)prow[t] * KP];
+                    const float dot = ref_dot(p, qq), s = fmaf(-lr, dot, lr * rr[t]);
+                    for (int f = 0; f < KP; ++f) {
+                        const float po = p[f], qo = qq[f];
+                        p[f] = fmaf(s, qo, c * po);
+                        qq[f] = fmaf(s, po, c * qo);
+                    }
+                }
+                bad = memcmp(out.data(), r2.data(), out.size() * 4) != 0;
+            }
+            printf("L=%d mode=%d (%s) n=%d: chain %.1f cycles/step, helper %.1f cycles/step%s\n", LG, mode,
+                   mode == 1 ? "chain alone" : mode == 2 ? "helper alone" : "chain + helper", n, (double)best[0] / n, (double)best[1] / n,
+                   mode == 1 ? "" : (bad ? "  MISMATCH" : "  bit-exact"));
+        }
+    return 0;
+}
