@@ -21,7 +21,7 @@
 #include <cstdint>
 
 #include "kernels.hpp"
-#include "solo_asm.hpp"
+#include "run_asm.hpp"
 
 #pragma clang fp contract(off)
 
@@ -103,111 +103,7 @@ __device__ __forceinline__ void lds_st(unsigned char* base, unsigned off, const 
     *reinterpret_cast<float4*>(base + off) = v;
 }
 
-// ---- hand-scheduled run loop (gfx950) ---------------------------------------------------
-// `pairs` x 2 run steps of one wave: resident q rows in v[100:103] / v[140:143] (alternating),
-// one p row prefetched a step ahead, entry words fetched one / two steps ahead.  Per step:
-// 3 dot ops, 4 DPP adds whose two required wait states are filled with the independent
-// scale / address / LDS-issue instructions (the address is one v_mad_u32_u16: low 16 bits of
-// the entry word x 16 + row base), 1 fma for s, 4 pk_fma, 1 store.  Arithmetic is
-// instruction for instruction what Cell::apply's run_step does in C++ (which remains the
-// reference for it and the RMSE path).  Fixed VGPRs v100..v143 are declared clobbered.
-//   ea      : LDS byte address of this lane group's entry of run step 0 (entry stride `EST`)
-//   rowbase : LDS byte address of row slot 0 plus this lane's 16-byte offset inside a row
-// Register map (the text is a macro, which cannot carry comments line by line):
-//   v138 entry pointer, v139 row base; v114 / v115 entry word `slots` of the even / odd step in
-//   flight, v[116:117] / v[118:119] its {lr*r, ce}; v112 / v113 p-row address, v[104:107] / v[108:111]
-//   p row (prefetched one step ahead); v[100:103] <-> v[140:143] resident q rows; v[120:121] chunk
-//   products, v132 dot, v[122:125] ce*q, v[126:129] ce*p, v130 s, v[134:137] p'.
-//   Step: wait for p and the entry words -> chunk dot (pk_mul, pk_fma, add) -> 4 DPP adds
-//   (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) interleaved with the next p address, the
-//   ce scalings, the p prefetch and the entry prefetches -> EXTRA: the xor-16 / xor-32 levels for
-//   32 / 64 lanes per rating -> s = fma(-lr, dot, lr*r) -> q' = fma(s, p, ce*q), p' = fma(s, q, ce*p)
-//   -> store p'.  The prologue loads step 0; a harmless rewrite of an entry word keeps "one LDS
-//   operation behind the reads" so that every pass can use the same counted wait.
-#define MFSGD_RUN_LOOP_ASM_TEXT(EXTRA) \
-        "v_mov_b32 v138, %[ea]\n\t" \
-        "v_mov_b32 v139, %[rb]\n\t" \
-        "ds_read_b32 v114, v138\n\t" \
-        "ds_read_b64 v[116:117], v138 offset:8\n\t" \
-        "ds_read_b32 v115, v138 offset:%c[e1]\n\t" \
-        "v_mov_b32 v100, %[q0]\n\t" \
-        "v_mov_b32 v101, %[q1]\n\t" \
-        "v_mov_b32 v102, %[q2]\n\t" \
-        "v_mov_b32 v103, %[q3]\n\t" \
-        "s_waitcnt lgkmcnt(2)\n\t" \
-        "v_and_b32 v133, 0xffff, v114\n\t" \
-        "v_lshl_add_u32 v112, v133, 4, v139\n\t" \
-        "ds_read_b128 v[104:107], v112\n\t" \
-        "ds_write_b32 v138, v114\n\t" \
-        "1:\n\t" \
-        "s_waitcnt lgkmcnt(1)\n\t" \
-        "v_pk_mul_f32 v[120:121], v[104:105], v[100:101]\n\t" \
-        "v_pk_fma_f32 v[120:121], v[106:107], v[102:103], v[120:121]\n\t" \
-        "v_add_f32 v132, v120, v121\n\t" \
-        "v_mad_u32_u16 v113, v115, 16, v139\n\t" \
-        "v_pk_mul_f32 v[122:123], v[116:117], v[100:101] op_sel:[1,0]\n\t" \
-        "v_add_f32_dpp v132, v132, v132 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "ds_read_b128 v[108:111], v113\n\t" \
-        "v_pk_mul_f32 v[124:125], v[116:117], v[102:103] op_sel:[1,0]\n\t" \
-        "v_add_f32_dpp v132, v132, v132 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "v_pk_mul_f32 v[126:127], v[116:117], v[104:105] op_sel:[1,0]\n\t" \
-        "v_pk_mul_f32 v[128:129], v[116:117], v[106:107] op_sel:[1,0]\n\t" \
-        "v_add_f32_dpp v132, v132, v132 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "ds_read_b32 v114, v138 offset:%c[e2]\n\t" \
-        "ds_read_b64 v[118:119], v138 offset:%c[e1p8]\n\t" \
-        "v_add_f32_dpp v132, v132, v132 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        EXTRA \
-        "v_fma_f32 v130, -%[lr], v132, v116\n\t" \
-        "v_pk_fma_f32 v[140:141], v[130:131], v[104:105], v[122:123] op_sel_hi:[0,1,1]\n\t" \
-        "v_pk_fma_f32 v[142:143], v[130:131], v[106:107], v[124:125] op_sel_hi:[0,1,1]\n\t" \
-        "v_pk_fma_f32 v[134:135], v[130:131], v[100:101], v[126:127] op_sel_hi:[0,1,1]\n\t" \
-        "v_pk_fma_f32 v[136:137], v[130:131], v[102:103], v[128:129] op_sel_hi:[0,1,1]\n\t" \
-        "s_sub_u32 %[n], %[n], 1\n\t" \
-        "ds_write_b128 v112, v[134:137]\n\t" \
-        "s_waitcnt lgkmcnt(1)\n\t" \
-        "v_pk_mul_f32 v[120:121], v[108:109], v[140:141]\n\t" \
-        "v_pk_fma_f32 v[120:121], v[110:111], v[142:143], v[120:121]\n\t" \
-        "v_add_f32 v132, v120, v121\n\t" \
-        "v_mad_u32_u16 v112, v114, 16, v139\n\t" \
-        "v_pk_mul_f32 v[122:123], v[118:119], v[140:141] op_sel:[1,0]\n\t" \
-        "v_add_f32_dpp v132, v132, v132 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "ds_read_b128 v[104:107], v112\n\t" \
-        "v_pk_mul_f32 v[124:125], v[118:119], v[142:143] op_sel:[1,0]\n\t" \
-        "v_add_f32_dpp v132, v132, v132 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "v_pk_mul_f32 v[126:127], v[118:119], v[108:109] op_sel:[1,0]\n\t" \
-        "v_pk_mul_f32 v[128:129], v[118:119], v[110:111] op_sel:[1,0]\n\t" \
-        "v_add_f32_dpp v132, v132, v132 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "ds_read_b32 v115, v138 offset:%c[e3]\n\t" \
-        "ds_read_b64 v[116:117], v138 offset:%c[e2p8]\n\t" \
-        "v_add_f32_dpp v132, v132, v132 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        EXTRA \
-        "v_fma_f32 v130, -%[lr], v132, v118\n\t" \
-        "v_pk_fma_f32 v[100:101], v[130:131], v[108:109], v[122:123] op_sel_hi:[0,1,1]\n\t" \
-        "v_pk_fma_f32 v[102:103], v[130:131], v[110:111], v[124:125] op_sel_hi:[0,1,1]\n\t" \
-        "v_pk_fma_f32 v[134:135], v[130:131], v[140:141], v[126:127] op_sel_hi:[0,1,1]\n\t" \
-        "v_pk_fma_f32 v[136:137], v[130:131], v[142:143], v[128:129] op_sel_hi:[0,1,1]\n\t" \
-        "v_add_u32 v138, %c[e2], v138\n\t" \
-        "s_cmp_lg_u32 %[n], 0\n\t" \
-        "ds_write_b128 v113, v[134:137]\n\t" \
-        "s_cbranch_scc1 1b\n\t" \
-        "s_waitcnt lgkmcnt(0)\n\t" \
-        "v_mov_b32 %[q0], v100\n\t" \
-        "v_mov_b32 %[q1], v101\n\t" \
-        "v_mov_b32 %[q2], v102\n\t" \
-        "v_mov_b32 %[q3], v103\n\t"
-
-// xor-16 / xor-32 levels of the dot reduction for L = 32 / 64 (see swap_add16 / swap_add32): v133 is free
-#define MFSGD_SWAP_ADD16 "v_mov_b32 v133, v132\n\ts_nop 1\n\tv_permlane16_swap_b32 v132, v133\n\ts_nop 1\n\tv_add_f32 v132, v132, v133\n\t"
-#define MFSGD_SWAP_ADD32 "v_mov_b32 v133, v132\n\ts_nop 1\n\tv_permlane32_swap_b32 v132, v133\n\ts_nop 1\n\tv_add_f32 v132, v132, v133\n\t"
-#define MFSGD_RUN_LOOP_ASM_OPERANDS                                                                                   \
-    : [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [n] "+s"(pairs)                              \
-    : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [e1] "n"(EST), [e2] "n"(2 * EST), [e3] "n"(3 * EST),              \
-      [e1p8] "n"(EST + 8), [e2p8] "n"(2 * EST + 8)                                                                     \
-    : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
-      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",  \
-      "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139",  \
-      "v140", "v141", "v142", "v143"
-
+// (the hand-scheduled run loop text lives in run_asm.hpp, shared with tools/ubench3.hip)
 template <int EST, int L>
 __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, const unsigned rowbase, int pairs,
                                              const float lr) {
@@ -223,7 +119,7 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
     rq = make_float4(q[0], q[1], q[2], q[3]);
 }
 
-// ---- solo run: chain wave / helper wave (solo_asm.hpp) -------------------------------------
+// ---- solo run: chain wave / helper wave (run_asm.hpp) -------------------------------------
 // `ea`: LDS byte address of the run's header record, `rowbase`: LDS byte address of row slot 0 plus
 // this lane's 16-byte offset inside a row, n >= 1 steps, c2 = {c, c} as one 64-bit scalar.
 template <int L>
@@ -453,7 +349,7 @@ struct Cell {
                 // Copy waves keep the barriers company: one per sub-round like everybody else.  Copy wave h
                 // is also the HELPER of apply wave (h + 1) % W -- a wave on another SIMD -- whenever that
                 // wave's sub-cell ends in a solo run: it follows the chain wave through the run's mailboxes,
-                // redoes the q recurrence and does all the stores (solo_asm.hpp).
+                // redoes the q recurrence and does all the stores (run_asm.hpp).
                 for (int s = 0; s < W; ++s) {
                     if constexpr (L >= 16) {
                         const uint2 sd = lsub[s * W + (wave + 1) % W];
@@ -797,12 +693,13 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     wg_barrier();
 
     // optional phase accounting (diagnostic launches only): shader cycles of wave 0 per phase
-    unsigned long long pacc[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [7]: the longest single "ratings" phase (its slowest cell)
     unsigned long long pt = 0;
     auto mark = [&](int k) {
         if (prof) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             pacc[k] += now - pt;
+            if (k == 4 && now - pt > pacc[7]) pacc[7] = now - pt;
             pt = now;
         }
     };
@@ -885,7 +782,7 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     if (ctl[0] != 0 && cx.tid == 0)  // raised during the last cell
         __hip_atomic_store((gu32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prof && cx.tid == 0)
-        for (int k = 0; k < 7; ++k) prof[(size_t)wg * 8 + k] = pacc[k];
+        for (int k = 0; k < 8; ++k) prof[(size_t)wg * 8 + k] = pacc[k];
 }
 
 template <int L, int W>

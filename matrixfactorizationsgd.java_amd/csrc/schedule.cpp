@@ -308,7 +308,7 @@ void pack_run(const Rat* rs, int n, const uint16_t* run_q, int nrun, int G, int 
 }
 
 // A SOLO run: the ratings of ONE item whose users are all distinct, as a compact stream of 16-byte
-// records (kernels.hip, solo_asm.hpp): [header][record 0] ... [record n-1][terminator], padded to
+// records (kernels.hip, run_asm.hpp): [header][record 0] ... [record n-1][terminator], padded to
 // whole steps.  record t = {lr * r_t, slots_{t+1}, mailbox (0xFFFFFFFF), r_t}; header = {0, slots_0,
 // 0, 0}; slots = p-row address | q-row address << 16; the address behind the last step is a zero row.
 // Every step decays with the same factor (no idle slots), so none is stored.

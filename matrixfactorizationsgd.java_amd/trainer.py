@@ -227,6 +227,7 @@ class MatrixFactorizationSGD:
         out = np.zeros(info["blocks"] * 8, np.uint64)
         n = C.c_int32()
         self._check(self._lib.mfsgd_debug_epoch_profile(self._handle(), _p(out, C.c_uint64), C.byref(n)))
+        self.last_slowest_cell = out[: n.value * 8].reshape(n.value, 8)[:, 7]  # longest single "ratings" phase per workgroup
         return out[: n.value * 8].reshape(n.value, 8)[:, :7]
 
     def debug_round_stamps(self, rnd):

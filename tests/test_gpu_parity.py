@@ -584,7 +584,7 @@ def test_reinit_after_training(mf, oracle, n_parts):
     assert np.array_equal(P, Po) and np.array_equal(Q, Qo)
 
 
-# ---- solo runs: chain wave + helper wave (solo_asm.hpp), and the one-wave forms of the same records ---
+# ---- solo runs: chain wave + helper wave (run_asm.hpp), and the one-wave forms of the same records ---
 @pytest.mark.parametrize("k,W", [(64, 1), (64, 2), (64, 4), (100, 2), (128, 2), (128, 4), (256, 2), (256, 4)])
 def test_solo_runs_every_geometry(mf, oracle, k, W):
     from mfsgd_amd import _lib
@@ -595,7 +595,7 @@ def test_solo_runs_every_geometry(mf, oracle, k, W):
     i = [7] * U + list(rng.integers(0, I, 9000))
     key = rng.permutation(np.unique(np.array(u) * I + np.array(i)))
     uu, ii, rr = key // I, key % I, rng.random(key.size) * 4 + 1
-    B = 12 if k == 256 else 5
+    B = 24 if k == 256 else 5  # k = 256: a cell holds ~140 rows
     for flags in (0, _lib.FLAG_ROUND_LAUNCH, _lib.FLAG_NO_SOLO):
         with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 3, blocks=B, waves=W, flags=flags) as m:
             m.set_ratings(uu, ii, rr)

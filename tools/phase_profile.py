@@ -13,14 +13,16 @@ import mfsgd_amd as mf  # noqa: E402
 name, scale = sys.argv[1], float(sys.argv[2])
 blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 waves = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+flags = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 w = mf.synth.workload(name, scale)
-with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], 0.01, 0.05, 3, blocks=blocks, waves=waves) as m:
+with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], 0.01, 0.05, 3, blocks=blocks, waves=waves, flags=flags) as m:
     m.set_ratings(w["u"], w["i"], w["r"])
     m.init_factors()
     info = m.schedule_info()
     m.fit(1, rmse=False)
     ms, _ = m.train_timed(5)
     prof = m.debug_epoch_profile().astype(np.float64)
+    slowest = m.last_slowest_cell.astype(np.float64)
 names = ["drain+issue", "tile wait", "barrier", "tile gather", "ratings", "publish", "own store"]
 tot = prof.sum(axis=1)
 nnz = info['nnz']
@@ -30,3 +32,6 @@ print(f"{name} x{scale}: B={info['blocks']} W={info['waves']} lds={info['lds_byt
 print("  phase cycles (mean over workgroups, share of the mean total %.0f):" % tot.mean())
 for k, nm in enumerate(names):
     print(f"    {nm:12s} {prof[:, k].mean():12.0f}  {100 * prof[:, k].mean() / tot.mean():5.1f} %")
+print(f"  slowest cell's ratings phase per workgroup: mean {slowest.mean():.0f} max {slowest.max():.0f} cycles; "
+      f"max_cell_steps {info['max_cell_steps']} -> {slowest.mean() / max(1, info['max_cell_steps']):.1f} cycles per step-equivalent; "
+      f"sum of phases {tot.mean():.0f} cycles per epoch -> {tot.mean() / (ms / 5) / 1e6:.2f} GHz")

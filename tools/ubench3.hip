@@ -1,4 +1,4 @@
-// Microbenchmark + correctness check of the SOLO run loops (csrc/solo_asm.hpp): one workgroup of
+// Microbenchmark + correctness check of the SOLO run loops (csrc/run_asm.hpp): one workgroup of
 // two waves on two SIMDs, wave 0 = chain wave, wave 1 = helper.  Prints cycles per step of the pair
 // (and of the chain wave alone, MODE=1: no helper, nothing stored) and compares every p row and the
 // q row with a plain host restatement of DESIGN.md section 3.
@@ -10,7 +10,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../matrixfactorizationsgd.java_amd/csrc/solo_asm.hpp"
+#include "../matrixfactorizationsgd.java_amd/csrc/run_asm.hpp"
 
 #ifndef LG
 #define LG 16  // lanes per rating
@@ -28,12 +28,17 @@
 constexpr int ROWB = 16 * LG;
 constexpr int NSTEP = (LG == 64 ? 120 : 300), NROWS = NSTEP + 2;  // p rows 0..NSTEP-1, q row NSTEP, zero row NSTEP+1
 constexpr int ENT_OFF = NROWS * ROWB;          // entries behind the rows
+constexpr int GS = 64 / LG;                    // slots per step of the (old) run loop
+constexpr int RUN_OFF = ENT_OFF + (NSTEP + 2) * 16;  // mode 3: run-loop entries, NSTEP + 2 steps x GS x 16 bytes
+constexpr int EXTRA_ZERO = NROWS;              // (mode 3 idle slots use the zero row too)
 
 __global__ void __launch_bounds__(128) k(const float* rows_in, const uint32_t* ent_in, float* rows_out, uint32_t* ent_out,
-                                         unsigned long long* cyc, int n_steps, float lr, float c, int mode) {
+                                         unsigned long long* cyc, int n_steps, float lr, float c, int mode,
+                                         const uint32_t* run_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     for (int x = threadIdx.x; x < NROWS * ROWB / 4; x += 128) ((float*)smem)[x] = rows_in[x];
     for (int x = threadIdx.x; x < (NSTEP + 2) * 4; x += 128) ((uint32_t*)(smem + ENT_OFF))[x] = ent_in[x];
+    for (int x = threadIdx.x; x < (NSTEP + 2) * GS * 4; x += 128) ((uint32_t*)(smem + RUN_OFF))[x] = run_in[x];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned rowbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem + (lane % LG) * 16;
@@ -42,7 +47,18 @@ __global__ void __launch_bounds__(128) k(const float* rows_in, const uint32_t* e
     unsigned long long t0 = 0, t1 = 0;
     int n = n_steps;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-    if (wave == 0 && mode != 2) {
+    if (wave == 0 && mode == 3) {
+        // the one-wave run loop (kernels.hip run_loop_asm): slot 0 carries the chain, the others idle
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int g = lane / LG;
+        const unsigned qaddr = (g == 0 ? NSTEP : NSTEP + 1) * ROWB + (lane % LG) * 16;
+        f4 q = *(const f4*)(smem + qaddr);
+        const unsigned ea = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + RUN_OFF) + g * 16;
+        int pairs = n_steps / 2;
+        constexpr int EST = GS * 16;
+        asm volatile(MFSGD_RUN_LOOP_ASM_TEXT(EXTRA) MFSGD_RUN_LOOP_ASM_OPERANDS);
+        if (g == 0) *(f4*)(smem + qaddr) = q;
+    } else if (wave == 0 && mode != 2) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 q = *(const f4*)(smem + NSTEP * ROWB + (lane % LG) * 16);
         asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA) MFSGD_SOLO_CHAIN_OPERANDS);
@@ -122,7 +138,7 @@ int main() {
     (void)hipMalloc(&d_cyc, 32);
     (void)hipMemcpy(d_in, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_ent, ent.data(), ent.size() * 4, hipMemcpyHostToDevice);
-    const size_t lds = (size_t)NROWS * ROWB + (NSTEP + 2) * 16;
+    const size_t lds = (size_t)NROWS * ROWB + (NSTEP + 2) * 16 + (size_t)(NSTEP + 2) * GS * 16;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // mode 2: mailboxes pre-filled with the reference's s_t -> the helper's own pace
     std::vector<uint32_t> ent2 = ent;
@@ -140,14 +156,35 @@ int main() {
             }
         }
     }
-    for (int mode = 0; mode < 3; ++mode)
+    // mode 3: the same chain as run-loop entries {slots, r, lr*r, ce}, slot 0 live, other slots idle
+    std::vector<uint32_t> run((NSTEP + 2) * GS * 4, 0);
+    for (int t = 0; t < NSTEP + 2; ++t)
+        for (int g = 0; g < GS; ++g) {
+            uint32_t* e = &run[(size_t)(t * GS + g) * 4];
+            const float one = 1.0f;
+            if (g == 0 && t < NSTEP) {
+                const float lrr = lr * rr[t];
+                e[0] = slots(prow[t]);
+                memcpy(&e[1], &rr[t], 4);
+                memcpy(&e[2], &lrr, 4);
+                memcpy(&e[3], &c, 4);
+            } else {
+                e[0] = (uint32_t)((NSTEP + 1) * LG) | ((uint32_t)((g == 0 ? NSTEP : NSTEP + 1) * LG) << 16) | 0x80000000u;
+                memcpy(&e[3], &one, 4);
+            }
+        }
+    uint32_t* d_run;
+    (void)hipMalloc(&d_run, run.size() * 4);
+    (void)hipMemcpy(d_run, run.data(), run.size() * 4, hipMemcpyHostToDevice);
+    for (int mode = 0; mode < 4; ++mode)
         for (int n : {NSTEP, NSTEP - 1, 1, 2}) {
+            if (mode == 3 && (n & 1)) continue;
             (void)hipMemcpy(d_ent, (mode == 2 ? ent2 : ent).data(), ent.size() * 4, hipMemcpyHostToDevice);
             unsigned long long best[2] = {~0ull, ~0ull}, h[4];
             std::vector<float> out(rows.size());
             for (int rep = 0; rep < 5; ++rep) {
                 (void)hipMemset(d_cyc, 0, 32);
-                hipLaunchKernelGGL(k, dim3(1), dim3(128), lds, 0, d_in, d_ent, d_out, d_ent_out, d_cyc, n, lr, c, mode);
+                hipLaunchKernelGGL(k, dim3(1), dim3(128), lds, 0, d_in, d_ent, d_out, d_ent_out, d_cyc, n, lr, c, mode, d_run);
                 (void)hipMemcpy(h, d_cyc, 32, hipMemcpyDeviceToHost);
                 if (h[2]) printf("helper gave up!\n");
                 for (int w = 0; w < 2; ++w) best[w] = h[w] < best[w] ? h[w] : best[w];
@@ -170,7 +207,7 @@ int main() {
                 bad = memcmp(out.data(), r2.data(), out.size() * 4) != 0;
             }
             printf("L=%d mode=%d (%s) n=%d: chain %.1f cycles/step, helper %.1f cycles/step%s\n", LG, mode,
-                   mode == 1 ? "chain alone" : mode == 2 ? "helper alone" : "chain + helper", n, (double)best[0] / n, (double)best[1] / n,
+                   mode == 1 ? "chain alone" : mode == 2 ? "helper alone" : mode == 3 ? "one-wave run loop" : "chain + helper", n, (double)best[0] / n, (double)best[1] / n,
                    mode == 1 ? "" : (bad ? "  MISMATCH" : "  bit-exact"));
         }
     return 0;
