@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo "
                     "(rehearsal: several ranks on one GPU, ring staged through host memory)")
+    ap.add_argument("--ring", default="native", help="native: the ring under the C-ABI (csrc/dsgd.cpp, RCCL send/recv on "
+                    "its own stream; torch.distributed/gloo only hands out the RCCL id and takes the max of the times); "
+                    "torch: the Python harness dsgd.py over torch.distributed P2P")
     ap.add_argument("--parts-per-rank", type=int, default=0, help="DSGD: item partitions a rank holds at a time (0 = 1)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debugging: run ONE rank of an N-GPU DSGD job on one "
                     "GPU without communication (per-rank compute time of that job)")
@@ -132,8 +135,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        if args.backend == "gloo":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        if args.backend == "gloo" or args.ring == "native":
+            dist.init_process_group("gloo", rank=rank, world_size=world)  # control plane only when the ring is native
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -160,6 +163,14 @@ def main():
                                          waves=args.waves, n_parts=n_parts,
                                          host_threads=host_threads(), flags=flags)
     t0 = time.time()
+    native = world > 1 and args.ring == "native" and args.backend != "gloo"
+    if native:
+        # the global partitioner: item partitions balanced by the GLOBAL rating counts (users are already
+        # dealt out evenly: every rank brought the same number of ratings)
+        deg_i = torch.from_numpy(np.bincount(w["i"], minlength=w["I"]).astype(np.int64))
+        dist.all_reduce(deg_i)
+        _, item_part = mfsgd_amd.dsgd_plan(np.ones(world, np.int64), deg_i.numpy(), n_parts)
+        m.set_item_partition(item_part)
     m.set_ratings(w["u"], w["i"], w["r"])
     infos = [m.schedule_info(p) for p in range(max(1, n_parts))]
     if rank == 0:
@@ -168,6 +179,32 @@ def main():
             f"lds={i0['lds_bytes']} steps={sum(i['total_steps'] for i in infos)} rows={sum(i['total_rows'] for i in infos)}")
 
     launches_per_epoch = sum((i["rounds"] if args.round_launch else 1) for i in infos if i["nnz"] > 0)
+
+    d_native, ring_note = None, ""
+    if native:
+        # the ring under the C-ABI; every rank must take the same path, so they agree on whether it came up
+        from mfsgd_amd.dsgd import NativeDSGD
+
+        why = ""
+        try:
+            obj = [NativeDSGD.unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            obj, why = [None], repr(e)
+        dist.broadcast_object_list(obj, src=0)
+        m.init_p_offset(SEED, rank * w["U"])
+        if obj[0] is not None:
+            try:
+                d_native = NativeDSGD(m, rank, world, obj[0])
+            except Exception as e:  # noqa: BLE001
+                why = repr(e)
+        ok = torch.tensor([1 if d_native is not None else 0], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not bool(ok[0]):
+            log(f"rank {rank}: the ring under the C-ABI did not come up ({why or 'another rank failed'}); "
+                "using the torch.distributed harness instead (see config.parallelism)")
+            if d_native is not None:
+                d_native.close()
+            d_native, native, ring_note = None, False, "-torch-ring-fallback"
 
     if vworld == 1:
         m.init_factors(SEED)
@@ -182,12 +219,38 @@ def main():
         elapsed_s = max(wall_s, dev_ms / 1e3)
         rmse1 = m.rmse()
         total_updates = nnz * args.steps
+    elif d_native is not None:
+        d = d_native
+        d.init_q(SEED, w["U"] * world)
+        rmse0 = d.rmse()
+        d.train(args.warmup, rmse=False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t_wall0 = time.perf_counter()
+        d.train(args.steps, rmse=False)  # returns when the compute and the communication stream are idle
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        wall_s = time.perf_counter() - t_wall0
+        tmax = torch.tensor([wall_s], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed_s = float(tmax[0])
+        dev_ms = elapsed_s * 1e3
+        launches = launches_per_epoch * args.steps
+        rmse1 = d.rmse()
+        total_updates = nnz * world * args.steps
+        d.close()
     else:
         from mfsgd_amd.dsgd import DSGD, HipBackend, TorchDistRing
 
         u_total = w["U"] * vworld
         m.init_p_offset(SEED, rank * w["U"])
-        ring = TorchDistRing(dist, rank, world)
+        # blocks travel over torch.distributed P2P: RCCL ("nccl") unless this is a gloo rehearsal
+        group = None
+        if world > 1 and args.backend != "gloo" and dist.get_backend() != "nccl":
+            group = dist.new_group(backend="nccl")
+        ring = TorchDistRing(dist, rank, world, group=group)
         if emu:
             # one rank of an `emu`-rank job: the ring shift is a local copy, every group is visited
             class _Loop(TorchDistRing):
@@ -268,7 +331,8 @@ def main():
             "sum_round_steps": sum(i["sum_round_steps"] for i in infos),
             "blocks": infos[0]["blocks"], "waves": infos[0]["waves"],
             "parts_per_rank": ppr, "emulated_world": emu,
-            "parallelism": "single" if world == 1 else f"dsgd{world}" + ("-gloo-rehearsal" if args.backend == "gloo" else ""),
+            "parallelism": "single" if world == 1 else f"dsgd{world}" + ("-gloo-rehearsal" if args.backend == "gloo" else "")
+                           + ("-native-rccl-ring" if native else "") + ring_note,
         },
         "rmse_before": rmse0,
         "rmse_after": rmse1,

@@ -251,6 +251,52 @@ int mfsgd_part_sse(mfsgd_handle* h, int32_t part, const float* q_block_dev, void
 /* Seeds P when this handle holds users [u_offset, u_offset + n_users) of a
  * larger problem: stream position of P row u is (u_offset + u) * k.           */
 int mfsgd_init_p_offset(mfsgd_handle* h, int64_t seed, int64_t u_offset);
+/* Waits for `stream` and reports whether a training launch of this partition gave up on a
+ * hand-off since the last check (MFSGD_ERR_HIP then: the factors are invalid).  mfsgd_part_train
+ * is asynchronous and cannot report that itself.                                             */
+int mfsgd_part_sync(mfsgd_handle* h, int32_t part, void* stream);
+/* Partition count, padded row length (floats) and device ordinal of a handle. */
+int mfsgd_get_parts(const mfsgd_handle* h, int32_t* n_parts, int32_t* kp, int32_t* device);
+
+/* ---- DSGD driver: the ring under the C-ABI (csrc/dsgd.cpp) -----------------------------------
+ * One process per GPU.  Each rank creates a handle with n_parts = world * m (m >= 1 partitions held
+ * at a time), installs the item map (mfsgd_set_item_partition) if it uses a plan, gives it ITS
+ * users' ratings and seeds P (mfsgd_init_p_offset); then
+ *     rank 0: mfsgd_dsgd_unique_id(id);  every rank receives the same 128 bytes (any transport)
+ *     mfsgd_dsgd_create(h, rank, world, id, &d)   -- collective (ncclCommInitRank)
+ *     mfsgd_dsgd_init_q(d, seed, u_total)         -- seeds the Q blocks this rank holds first
+ *     mfsgd_dsgd_train(d, epochs, rmse)           -- collective
+ * An epoch is `world` sub-epochs: train the m partitions of the group held (one after another:
+ * they share this rank's users), pass each block to rank - 1 as soon as ITS training has finished
+ * and receive the next one from rank + 1: ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on
+ * a communication stream, ordered against the compute stream with events, no host
+ * synchronisation inside an epoch.  RCCL is bound at run time (librccl.so.1, or
+ * MFSGD_RCCL_LIBRARY); without it these calls return MFSGD_ERR_UNSUPPORTED.
+ * Java: MatrixFactorizationSGD.trainDistributed(...).               */
+typedef struct mfsgd_dsgd mfsgd_dsgd;
+#define MFSGD_DSGD_ID_BYTES 128
+int mfsgd_dsgd_unique_id(void* id_out /* MFSGD_DSGD_ID_BYTES */);
+int mfsgd_dsgd_create(mfsgd_handle* h, int32_t rank, int32_t world, const void* id, mfsgd_dsgd** out);
+void mfsgd_dsgd_destroy(mfsgd_dsgd* d);
+/* d == NULL: message of the last failed mfsgd_dsgd_create / mfsgd_dsgd_unique_id on this thread. */
+const char* mfsgd_dsgd_last_error(const mfsgd_dsgd* d);
+/* Seeds the blocks of the group this rank holds first (partitions rank*m .. rank*m + m - 1) as
+ * the single-device init would: stream position of Q row i is (u_total + i) * k.             */
+int mfsgd_dsgd_init_q(mfsgd_dsgd* d, int64_t seed, int64_t u_total);
+/* Slot j (0 <= j < m) of the group currently held -- between epochs that is the home group:
+ * dense rows x k host arrays, rows = mfsgd_part_rows of that partition.                      */
+int mfsgd_dsgd_set_q(mfsgd_dsgd* d, int32_t j, const float* block_host);
+int mfsgd_dsgd_get_q(mfsgd_dsgd* d, int32_t j, int32_t* part, int32_t* rows, float* block_host);
+/* `epochs` DSGD epochs; rmse_per_epoch (nullable) receives the global RMSE after each (one
+ * read-only rotation and a 2-double all-reduce).  Blocks until the device is idle.           */
+int mfsgd_dsgd_train(mfsgd_dsgd* d, int32_t epochs, double* rmse_per_epoch);
+int mfsgd_dsgd_rmse(mfsgd_dsgd* d, double* out);
+/* bench.py: `epochs` epochs bracketed by HIP events on the compute stream (the last blocks'
+ * arrival included); no RMSE pass.                                                            */
+int mfsgd_dsgd_train_timed(mfsgd_dsgd* d, int32_t epochs, double* elapsed_ms);
+/* All-reduce of two doubles over the ranks (op 0 = sum, 1 = max): what a host needs for global
+ * counts and max-over-ranks timings without a second communication library.                  */
+int mfsgd_dsgd_allreduce(mfsgd_dsgd* d, double* values2, int32_t op);
 
 #ifdef __cplusplus
 }

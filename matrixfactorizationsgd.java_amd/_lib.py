@@ -107,6 +107,19 @@ SIGNATURES = {
     "mfsgd_part_train": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p]),
     "mfsgd_part_sse": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, _f64p]),
     "mfsgd_init_p_offset": (C.c_int, [_H, C.c_int64, C.c_int64]),
+    "mfsgd_part_sync": (C.c_int, [_H, C.c_int32, C.c_void_p]),
+    "mfsgd_get_parts": (C.c_int, [_H, _i32p, _i32p, _i32p]),
+    "mfsgd_dsgd_unique_id": (C.c_int, [C.c_void_p]),
+    "mfsgd_dsgd_create": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(_H)]),
+    "mfsgd_dsgd_destroy": (None, [_H]),
+    "mfsgd_dsgd_last_error": (C.c_char_p, [_H]),
+    "mfsgd_dsgd_init_q": (C.c_int, [_H, C.c_int64, C.c_int64]),
+    "mfsgd_dsgd_set_q": (C.c_int, [_H, C.c_int32, _f32p]),
+    "mfsgd_dsgd_get_q": (C.c_int, [_H, C.c_int32, _i32p, _i32p, _f32p]),
+    "mfsgd_dsgd_train": (C.c_int, [_H, C.c_int32, _f64p]),
+    "mfsgd_dsgd_rmse": (C.c_int, [_H, _f64p]),
+    "mfsgd_dsgd_train_timed": (C.c_int, [_H, C.c_int32, _f64p]),
+    "mfsgd_dsgd_allreduce": (C.c_int, [_H, _f64p, C.c_int32]),
 }
 
 _lib = None
@@ -131,6 +144,22 @@ def _share_torch_hip_runtime():
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
     except Exception:  # a broken torch installation must not keep the library from loading
+        pass
+
+
+def share_torch_rccl():
+    """One RCCL per process where possible: libmfsgd binds librccl.so.1 at run time (dlopen); loading
+    PyTorch's bundled copy first makes that resolve to the copy torch itself uses (SONAME match)."""
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
         pass
 
 

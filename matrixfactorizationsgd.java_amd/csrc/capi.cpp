@@ -1033,6 +1033,23 @@ int mfsgd_part_train(mfsgd_handle* h, int32_t part, float* q_block_dev, void* st
     return launch_epoch(h, h->parts[(size_t)part], q_block_dev, static_cast<hipStream_t>(stream));
 }
 
+int mfsgd_part_sync(mfsgd_handle* h, int32_t part, void* stream) {
+    if (!h) return MFSGD_ERR_INVALID_ARG;
+    if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_sync: bad partition");
+    if (!h->device_ready || !h->have_ratings) return MFSGD_OK;  // nothing can have been launched
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return check_abort(h, h->parts[(size_t)part]);
+}
+
+int mfsgd_get_parts(const mfsgd_handle* h, int32_t* n_parts, int32_t* kp, int32_t* device) {
+    if (!h) return MFSGD_ERR_INVALID_ARG;
+    if (n_parts) *n_parts = h->n_parts;
+    if (kp) *kp = h->geo.kp;
+    if (device) *device = h->cfg.device;
+    return MFSGD_OK;
+}
+
 int mfsgd_part_sse(mfsgd_handle* h, int32_t part, const float* q_block_dev, void* stream, double* sse) {
     if (!h || !q_block_dev || !sse) return fail(h, MFSGD_ERR_INVALID_ARG, "part_sse: null argument");
     if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_sse: bad partition");

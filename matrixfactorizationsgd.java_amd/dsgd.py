@@ -56,11 +56,109 @@ class HipBackend:
         self.torch.cuda.synchronize(self.device)
 
 
+class NativeDSGD:
+    """The product path for N GPUs: the ring under the C-ABI (csrc/dsgd.cpp, mfsgd_dsgd_*): RCCL
+    ncclSend / ncclRecv in a group on a communication stream, ordered against the training stream
+    with events.  This class is the thin binding a Java / C++ host would write (INTEGRATION.md
+    section 5); `trainer` is a MatrixFactorizationSGD created with n_parts = world * m that already
+    has its ratings and its P seed.  `unique_id` (128 bytes from NativeDSGD.unique_id() on one
+    rank) reaches the other ranks by whatever transport the host has."""
+
+    def __init__(self, trainer, rank, world, unique_id):
+        import ctypes as C
+
+        from . import _lib
+
+        self._C = C
+        self._lib = _lib.load_library()
+        _lib.share_torch_rccl()
+        self.t = trainer
+        self.rank, self.world = int(rank), int(world)
+        self.m = trainer.n_parts // self.world
+        self._d = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        rc = self._lib.mfsgd_dsgd_create(trainer._handle(), self.rank, self.world, buf, C.byref(self._d))
+        if rc != 0:
+            from .trainer import MfsgdError
+
+            raise MfsgdError(rc, self._lib.mfsgd_dsgd_last_error(None).decode())
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+
+        from . import _lib
+        from .trainer import MfsgdError
+
+        lib = _lib.load_library()
+        _lib.share_torch_rccl()
+        buf = C.create_string_buffer(128)
+        rc = lib.mfsgd_dsgd_unique_id(buf)
+        if rc != 0:
+            raise MfsgdError(rc, lib.mfsgd_dsgd_last_error(None).decode())
+        return buf.raw
+
+    def _check(self, rc):
+        if rc != 0:
+            from .trainer import MfsgdError
+
+            raise MfsgdError(rc, self._lib.mfsgd_dsgd_last_error(self._d).decode())
+
+    def close(self):
+        if getattr(self, "_d", None):
+            self._lib.mfsgd_dsgd_destroy(self._d)
+            self._d = self._C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def init_q(self, seed, u_total):
+        self._check(self._lib.mfsgd_dsgd_init_q(self._d, int(seed), int(u_total)))
+
+    def train(self, epochs, rmse=True):
+        C = self._C
+        out = np.zeros(int(epochs), np.float64)
+        self._check(self._lib.mfsgd_dsgd_train(self._d, int(epochs), out.ctypes.data_as(C.POINTER(C.c_double)) if rmse else None))
+        return out if rmse else None
+
+    def train_timed(self, epochs):
+        ms = self._C.c_double()
+        self._check(self._lib.mfsgd_dsgd_train_timed(self._d, int(epochs), self._C.byref(ms)))
+        return ms.value
+
+    def rmse(self):
+        out = self._C.c_double()
+        self._check(self._lib.mfsgd_dsgd_rmse(self._d, self._C.byref(out)))
+        return out.value
+
+    def allreduce(self, a, b, op="sum"):
+        C = self._C
+        v = np.array([a, b], np.float64)
+        self._check(self._lib.mfsgd_dsgd_allreduce(self._d, v.ctypes.data_as(C.POINTER(C.c_double)), 0 if op == "sum" else 1))
+        return float(v[0]), float(v[1])
+
+    def home_blocks(self):
+        """{partition: rows x k host copy of its Q block} of the group held (home between epochs)."""
+        C = self._C
+        out = {}
+        for j in range(self.m):
+            part, rows = C.c_int32(), C.c_int32()
+            self._check(self._lib.mfsgd_dsgd_get_q(self._d, j, C.byref(part), C.byref(rows), None))
+            blk = np.empty((rows.value, self.t.k), np.float32)
+            self._check(self._lib.mfsgd_dsgd_get_q(self._d, j, C.byref(part), C.byref(rows),
+                                                   blk.ctypes.data_as(C.POINTER(C.c_float))))
+            out[part.value] = blk
+        return out
+
+
 class TorchDistRing:
     """Ring shift over torch.distributed (backend "nccl" = RCCL on ROCm, or gloo on CPU)."""
 
-    def __init__(self, dist, rank, world):
-        self.dist, self.rank, self.world = dist, rank, world
+    def __init__(self, dist, rank, world, group=None):
+        self.dist, self.rank, self.world, self.group = dist, rank, world, group  # group: the P2P group (None = default)
 
     def shift(self, send_block, recv_block):
         """send to rank-1, receive from rank+1."""
@@ -68,7 +166,7 @@ class TorchDistRing:
             recv_block.copy_(send_block)
             return
         d = self.dist
-        if send_block.is_cuda and d.get_backend() == "gloo":
+        if send_block.is_cuda and d.get_backend(self.group) == "gloo":
             # rehearsal mode (several ranks sharing one GPU, where RCCL cannot run):
             # stage through host memory.  The production path is the branch below.
             hs, hr = send_block.cpu(), recv_block.cpu()
@@ -77,8 +175,8 @@ class TorchDistRing:
                 req.wait()
             recv_block.copy_(hr)
             return
-        ops = [d.P2POp(d.isend, send_block, (self.rank - 1) % self.world),
-               d.P2POp(d.irecv, recv_block, (self.rank + 1) % self.world)]
+        ops = [d.P2POp(d.isend, send_block, (self.rank - 1) % self.world, group=self.group),
+               d.P2POp(d.irecv, recv_block, (self.rank + 1) % self.world, group=self.group)]
         for req in d.batch_isend_irecv(ops):
             req.wait()
 

@@ -611,3 +611,60 @@ def test_solo_runs_on_the_bench_shape(mf, oracle):
         m.set_ratings(w["u"], w["i"], w["r"])
         assert int((m.debug_schedule()[2][:, 0] >> 16).sum()) > 0
     _run(mf, oracle, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"], epochs=2)
+
+
+# ---- the DSGD driver under the C-ABI (csrc/dsgd.cpp): RCCL self-ring on this one GPU ----------------
+@pytest.mark.parametrize("m,k", [(1, 64), (3, 64), (4, 128)])
+def test_native_dsgd_world1_self_ring(mf, oracle, m, k):
+    """world = 1: ncclSend / ncclRecv to itself move every block through both buffers; with m
+    partitions the result must equal the sequential definition (and, for m = 1, mfsgd_train)."""
+    from mfsgd_amd.dsgd import NativeDSGD, assemble_q
+
+    rng = np.random.default_rng(m * 100 + k)
+    U, I, n, epochs = 700, 500, 40000, 3
+    key = rng.choice(U * I, n, replace=False)
+    u, i, r = (key // I).astype(np.int32), (key % I).astype(np.int32), (rng.random(n) * 4 + 1).astype(np.float32)
+    n_parts = max(m, 2)  # the smallest partitioned handle has two partitions
+    with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 5, n_parts=n_parts) as t:
+        t.set_ratings(u, i, r)
+        t.init_p_offset(5, 0)
+        with NativeDSGD(t, 0, 1, NativeDSGD.unique_id()) as d:
+            assert d.m == n_parts
+            d.init_q(5, U)
+            rm0 = d.rmse()
+            rm = d.train(epochs)
+            blocks = d.home_blocks()
+            tot, cnt = d.allreduce(1.5, 2.0)
+            assert (tot, cnt) == (1.5, 2.0)
+            ms = d.train_timed(1)
+            assert ms > 0
+            P1, _ = t.get_factors()
+        orders = [t.order(p)[0] for p in range(n_parts)]
+    Po, Qo = oracle.init_factors(U, I, k, 5)
+    assert abs(oracle.rmse(Po, Qo, u, i, r) - rm0) <= 1e-9
+    ref = []
+    for _ in range(epochs):
+        for p in range(n_parts):
+            oracle.sgd_pass_ordered(Po, Qo, u, i, r, orders[p], LR, LAM)
+        ref.append(oracle.rmse(Po, Qo, u, i, r))
+    Q = assemble_q(blocks, I, k, n_parts)
+    assert np.array_equal(Q, Qo), "Q blocks after the self-ring differ from the sequential definition"
+    np.testing.assert_allclose(rm, ref, rtol=1e-9)
+    for p in range(n_parts):  # the timed epoch on top
+        oracle.sgd_pass_ordered(Po, Qo, u, i, r, orders[p], LR, LAM)
+    assert np.array_equal(P1, Po)
+
+
+def test_native_dsgd_rejects_bad_arguments(mf):
+    from mfsgd_amd.dsgd import NativeDSGD
+
+    uid = NativeDSGD.unique_id()
+    assert len(uid) == 128
+    with mf.MatrixFactorizationSGD(10, 9, 8, LR, LAM, 1, n_parts=3) as t:
+        with pytest.raises(mf.MfsgdError):
+            NativeDSGD(t, 0, 1, uid)  # no ratings yet
+        t.set_ratings([0, 1, 2], [0, 1, 2], [1.0, 2.0, 3.0])
+        with pytest.raises(mf.MfsgdError):
+            NativeDSGD(t, 0, 2, uid)  # 3 partitions cannot be dealt to 2 ranks
+        with pytest.raises(mf.MfsgdError):
+            NativeDSGD(t, 2, 1, uid)  # rank out of range
