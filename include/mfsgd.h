@@ -203,6 +203,12 @@ int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cell
  * own rows; word 7 unused.  out must hold blocks x 8 words.  It DOES apply the epoch.           */
 int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgroups);
 
+/* Diagnostic (not part of the Java surface): occupies the LDS of all but four CUs for `milliseconds` (<= 5000)
+ * with a spinning kernel on a side stream, asynchronously -- what a foreign kernel sharing the GPU
+ * looks like to the persistent epoch kernel.  Tests use it to force the "workgroups not co-resident"
+ * path: the epoch kernel gives up before touching anything and the epoch runs as round launches. */
+int mfsgd_debug_occupy(mfsgd_handle* h, int32_t milliseconds);
+
 /* Diagnostic (not part of the Java surface): runs training round `round` once with
  * phase stamps; out receives blocks x 6 values per workgroup: shader-clock at
  * start, after gather, after the rating steps, after scatter, then the 100 MHz

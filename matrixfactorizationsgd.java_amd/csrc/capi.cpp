@@ -79,6 +79,7 @@ struct mfsgd_handle {
     bool device_ready = false;
     int n_cu = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;  // diagnostics only (mfsgd_debug_occupy)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     mutable std::string err;
 };
@@ -188,8 +189,11 @@ void default_item_map(mfsgd_handle* h) {
     h->custom_item_map = false;
 }
 
-size_t sync_bytes(const Part& p) { return ((size_t)p.sched.B * kDoneStride + 4) * sizeof(unsigned); }
-unsigned* abort_word(const Part& p) { return static_cast<unsigned*>(p.d_sync.p) + (size_t)p.sched.B * kDoneStride; }
+// d_sync: done[B] words (kDoneStride apart), then 4 words zeroed with them before every launch (the
+// first counts the workgroups that have arrived), then {abort code, launches that started, -, -}.
+size_t sync_bytes(const Part& p) { return ((size_t)p.sched.B * kDoneStride + 8) * sizeof(unsigned); }
+size_t sync_zeroed_bytes(const Part& p) { return ((size_t)p.sched.B * kDoneStride + 4) * sizeof(unsigned); }
+unsigned* abort_word(const Part& p) { return static_cast<unsigned*>(p.d_sync.p) + (size_t)p.sched.B * kDoneStride + 4; }
 
 int ensure_part_on_device(mfsgd_handle* h, Part& p) {
     if (p.on_device) return MFSGD_OK;
@@ -261,7 +265,10 @@ int probe_persistent(mfsgd_handle* h, Part& p) {
         (void)hipGetLastError();
         return MFSGD_OK;  // fall back to one launch per round
     }
-    const long np = (long)per_cu * h->n_cu;
+    long np = (long)per_cu * h->n_cu;
+    // test hook: pretend the chip holds this many times more workgroups than it does, so that the
+    // residency check of the epoch kernel has to fail (tests/test_gpu_parity.py)
+    if (const char* f = std::getenv("MFSGD_TEST_OVERSUBSCRIBE")) np *= std::max(1, std::atoi(f));
     p.persistent_np = (int)std::min<long>(np, p.sched.B);
     return MFSGD_OK;
 }
@@ -271,7 +278,7 @@ int launch_epoch_body(mfsgd_handle* h, Part& p, float* Q, hipStream_t st) {
         CellLaunch a = make_launch(h, p, Q);
         a.grid = p.persistent_np;
         // flags are counted within the launch: zero them (and the abort word) every time
-        HIPCHK(h, hipMemsetAsync(p.d_sync.p, 0, sync_bytes(p) - sizeof(unsigned) * 4, st));
+        HIPCHK(h, hipMemsetAsync(p.d_sync.p, 0, sync_zeroed_bytes(p), st));
         HIPCHK(h, launch_epoch_persistent(h->geo.L, p.sched.W, a, p.sched.B, static_cast<unsigned*>(p.d_sync.p),
                                           abort_word(p), st));
         return MFSGD_OK;
@@ -313,16 +320,41 @@ int launch_epoch(mfsgd_handle* h, Part& p, float* Q, hipStream_t st) {
     return MFSGD_OK;
 }
 
-// After a synchronisation point: did a persistent launch give up on a hand-off?
-int check_abort(mfsgd_handle* h, Part& p) {
+// After a synchronisation point: did a persistent launch give up?  Returns MFSGD_OK, MFSGD_ERR_HIP (a
+// hand-off or a solo helper timed out mid-epoch: the factors are invalid), or kNotResident: the
+// launch found its workgroups not co-resident and did NOTHING (nor did any launch queued behind it);
+// *started receives the number of launches since the last check that did run.
+constexpr int kNotResident = 1;
+int check_abort(mfsgd_handle* h, Part& p, unsigned* started = nullptr) {
+    if (started) *started = 0;
     if (p.persistent_np <= 0 || !p.d_sync.p) return MFSGD_OK;
-    unsigned w = 0;
-    HIPCHK(h, hipMemcpy(&w, abort_word(p), sizeof w, hipMemcpyDeviceToHost));
-    if (w != 0) {
-        (void)hipMemset(abort_word(p), 0, sizeof w);
+    unsigned w[2] = {0, 0};
+    HIPCHK(h, hipMemcpy(w, abort_word(p), sizeof w, hipMemcpyDeviceToHost));
+    if (started) *started = w[1];
+    if (w[0] != 0 || w[1] != 0) (void)hipMemset(abort_word(p), 0, sizeof w);
+    if (w[0] == 2u) return kNotResident;
+    if (w[0] != 0)
         return fail(h, MFSGD_ERR_HIP, "persistent epoch kernel timed out waiting for a tile hand-off (results invalid)");
-    }
     return MFSGD_OK;
+}
+
+// The persistent kernel could not get all its workgroups onto the chip (something else is running
+// there): from now on this partition is trained with one launch per round, which needs no co-residency.
+void give_up_persistence(mfsgd_handle* h, Part& p) {
+    (void)hipDeviceSynchronize();
+    drop_graphs(p);
+    p.persistent_np = 0;
+    (void)h;
+}
+
+// For callers that cannot re-run what was skipped (asynchronous DSGD sub-epochs on caller-owned blocks).
+int check_abort_strict(mfsgd_handle* h, Part& p) {
+    const int rc = check_abort(h, p);
+    if (rc != kNotResident) return rc;
+    give_up_persistence(h, p);
+    return fail(h, MFSGD_ERR_HIP,
+                "persistent epoch kernel: workgroups not co-resident (another kernel holds the GPU); the launch and those "
+                "queued behind it were NOT applied -- this partition now uses one launch per round, repeat the epoch");
 }
 
 int launch_sse(mfsgd_handle* h, Part& p, const float* Q, hipStream_t st) {
@@ -349,7 +381,24 @@ int part_sse_sync(mfsgd_handle* h, Part& p, const float* Q, hipStream_t st, doub
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(sse, p.d_sse_out.p, sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
-    return check_abort(h, p);
+    return check_abort_strict(h, p);
+}
+
+int launch_epoch(mfsgd_handle* h, Part& p, float* Q, hipStream_t st);
+
+// `launched` epochs of a single-partition handle are in flight on st: wait, and if the persistent
+// kernel found itself not resident (it then did nothing, nor did the launches behind it), run what
+// is missing as one launch per round.
+int settle_epochs(mfsgd_handle* h, Part& p, float* Q, hipStream_t st, int launched) {
+    HIPCHK(h, hipStreamSynchronize(st));
+    unsigned started = 0;
+    int rc = check_abort(h, p, &started);
+    if (rc != kNotResident) return rc;
+    give_up_persistence(h, p);
+    for (int e = (int)std::min<unsigned>(started, (unsigned)launched); e < launched; ++e)
+        if ((rc = launch_epoch(h, p, Q, st))) return rc;
+    HIPCHK(h, hipStreamSynchronize(st));
+    return MFSGD_OK;
 }
 
 int prepare_compute(mfsgd_handle* h) {
@@ -448,6 +497,10 @@ void mfsgd_destroy(mfsgd_handle* h) {
     h->dQ.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->side_stream) {
+        (void)hipStreamSynchronize(h->side_stream);
+        (void)hipStreamDestroy(h->side_stream);
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -690,12 +743,12 @@ int mfsgd_train(mfsgd_handle* h, int32_t epochs, double* rmse_per_epoch) {
         if ((rc = launch_epoch(h, p, Q, h->stream))) return rc;
         if (rmse_per_epoch) {
             double sse = 0.0;
+            if ((rc = settle_epochs(h, p, Q, h->stream, 1))) return rc;
             if ((rc = part_sse_sync(h, p, Q, h->stream, &sse))) return rc;
             rmse_per_epoch[e] = p.sched.nnz > 0 ? std::sqrt(sse / (double)p.sched.nnz) : 0.0;
         }
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return check_abort(h, p);
+    return settle_epochs(h, p, Q, h->stream, rmse_per_epoch ? 0 : epochs);
 }
 
 int mfsgd_train_timed(mfsgd_handle* h, int32_t epochs, double* elapsed_ms, int64_t* launches) {
@@ -715,7 +768,7 @@ int mfsgd_train_timed(mfsgd_handle* h, int32_t epochs, double* elapsed_ms, int64
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *elapsed_ms = (double)ms;
     if (launches) *launches = p.sched.nnz > 0 ? (int64_t)epochs * (p.persistent_np > 0 ? 1 : p.sched.B) : 0;
-    return check_abort(h, p);
+    return check_abort_strict(h, p);  // a timing of launches that did nothing would be meaningless
 }
 
 int mfsgd_rmse(mfsgd_handle* h, double* out) {
@@ -914,12 +967,24 @@ int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgro
     a.diag = true;
     a.sse_partial = static_cast<double*>(p.d_sse_partial.p);
     HIPCHK(h, hipMemsetAsync(p.d_sse_partial.p, 0, words * sizeof(uint64_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(p.d_sync.p, 0, sync_bytes(p) - sizeof(unsigned) * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(p.d_sync.p, 0, sync_zeroed_bytes(p), h->stream));
     HIPCHK(h, launch_epoch_persistent(h->geo.L, p.sched.W, a, p.sched.B, static_cast<unsigned*>(p.d_sync.p), abort_word(p), h->stream));
     HIPCHK(h, hipMemcpyAsync(out, p.d_sse_partial.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *n_workgroups = p.persistent_np;
-    return check_abort(h, p);
+    return check_abort_strict(h, p);
+}
+
+int mfsgd_debug_occupy(mfsgd_handle* h, int32_t milliseconds) {
+    if (!h || milliseconds < 0 || milliseconds > 5000) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_occupy: bad argument");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    if (!h->side_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    // one workgroup on all but four CUs, each with (nearly) the whole LDS: nothing that needs LDS fits beside
+    // it, and a persistent launch of more than a handful of workgroups finds only SOME of them resident
+    HIPCHK(h, launch_occupy(std::max(1, h->n_cu - 4), 160 * 1024 - 1024, (unsigned long long)milliseconds * 100000ull,
+                            h->side_stream));
+    return MFSGD_OK;
 }
 
 int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint64_t* out) {
@@ -1039,7 +1104,7 @@ int mfsgd_part_sync(mfsgd_handle* h, int32_t part, void* stream) {
     if (!h->device_ready || !h->have_ratings) return MFSGD_OK;  // nothing can have been launched
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    return check_abort(h, h->parts[(size_t)part]);
+    return check_abort_strict(h, h->parts[(size_t)part]);
 }
 
 int mfsgd_get_parts(const mfsgd_handle* h, int32_t* n_parts, int32_t* kp, int32_t* device) {

@@ -654,7 +654,37 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     Cell<L, W, NH> cx;
     cx.init_thread();
     cx.fail_flag = ctl;
-    if (cx.tid == 0) ctl[0] = 0;
+    // Residency check before anything is touched: every workgroup of the launch announces itself and
+    // waits until all NP have (abort_word[-4] counts arrivals; the host zeroes it with the flags).  The
+    // hand-off protocol below needs all of them on the chip at once; when they are not -- another
+    // kernel holds CUs -- the launch gives up HERE, with the factors untouched (abort code 2), and the
+    // host runs the epoch as one launch per round instead.  A launch that finds the abort word already
+    // set (an earlier launch of the same stream gave up) does nothing either.
+    if (cx.tid == 0) {
+        unsigned bad = __hip_atomic_load((gu32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bad == 0u) {
+            gu32* arrive = (gu32*)(abort_word - 4);
+            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)NP) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((++spins & 63u) == 0u) {
+                    bad = __hip_atomic_load((gu32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (bad == 0u && spins > (1u << 19)) {
+                        unsigned expected = 0u;  // only the first one to give up sets the code
+                        __hip_atomic_compare_exchange_strong((gu32*)abort_word, &expected, 2u, __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        bad = 2u;
+                    }
+                    if (bad != 0u) break;
+                }
+            }
+        }
+        ctl[0] = bad != 0u ? 1u : 0u;
+        ctl[1] = bad;
+    }
+    wg_barrier();
+    if (ctl[0] != 0) return;  // uniform; nothing has been modified
 
     // This workgroup's work list: (round R, block b) for b = blockIdx.x, +NP, ... in round order,
     // and within a cell its chunks in chain order.
@@ -744,6 +774,7 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
             if (cx.tid == 0) __hip_atomic_store((gu32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
+        (void)0;
         const Item it2 = next_item(it1, cd1);
         if (work) cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
         // descriptor used two iterations from now: a scalar load issued here, behind every gather of
@@ -781,6 +812,8 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     }
     if (ctl[0] != 0 && cx.tid == 0)  // raised during the last cell
         __hip_atomic_store((gu32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wg == 0 && cx.tid == 0)  // launches that got past the residency check (the host counts on it when one did not)
+        __hip_atomic_fetch_add((gu32*)(abort_word + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prof && cx.tid == 0)
         for (int k = 0; k < 8; ++k) prof[(size_t)wg * 8 + k] = pacc[k];
 }
@@ -1002,6 +1035,21 @@ hipError_t sse_L(int W, const CellLaunch& a, int n_cells, hipStream_t st) {
         case 8: return sse_LW<L, 8>(a, n_cells, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+// Diagnostic: workgroups that hold a whole CU's LDS and spin for `ticks` of the 100 MHz clock.
+__global__ void __launch_bounds__(64) occupy_kernel(const unsigned long long ticks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    smem[threadIdx.x] = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+hipError_t launch_occupy(int workgroups, int lds_bytes, unsigned long long ticks, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)workgroups), dim3(64), (size_t)lds_bytes, st, ticks);
+    return hipGetLastError();
 }
 
 hipError_t epoch_blocks_per_cu(int L, int W, const CellLaunch& a, int* blocks_per_cu) {

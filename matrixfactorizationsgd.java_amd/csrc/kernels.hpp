@@ -42,6 +42,9 @@ hipError_t launch_reduce_sse(const double* partial, int64_t n, double* out, hipS
 hipError_t launch_predict(int L, const float* P, const float* Q, const int32_t* u, const int32_t* i,
                           float* out, int64_t n, hipStream_t st);
 
+// Diagnostic (tests): `workgroups` one-wave workgroups, each holding lds_bytes of LDS, spin for `ticks` x 10 ns.
+hipError_t launch_occupy(int workgroups, int lds_bytes, unsigned long long ticks, hipStream_t st);
+
 // recommend.hip: scores of nb users against every item, top `topn` of each into out_s / out_i.
 hipError_t recommend_batch(int L, const float* P, const float* Q, const int32_t* d_users, int nb, int32_t n_items,
                            int32_t topn, float* s_in, float* s_out, int32_t* id_in, int32_t* id_out, long long* d_off,

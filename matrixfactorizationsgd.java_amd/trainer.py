@@ -230,6 +230,10 @@ class MatrixFactorizationSGD:
         self.last_slowest_cell = out[: n.value * 8].reshape(n.value, 8)[:, 7]  # longest single "ratings" phase per workgroup
         return out[: n.value * 8].reshape(n.value, 8)[:, :7]
 
+    def debug_occupy(self, milliseconds):
+        """Holds every CU's LDS for a while on a side stream (diagnostic; asynchronous)."""
+        self._check(self._lib.mfsgd_debug_occupy(self._handle(), int(milliseconds)))
+
     def debug_round_stamps(self, rnd):
         """[blocks, 6] stamps of one training round (diagnostic): 4 shader-clock phase
         stamps, then the 100 MHz constant clock at start and end."""

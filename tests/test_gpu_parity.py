@@ -668,3 +668,32 @@ def test_native_dsgd_rejects_bad_arguments(mf):
             NativeDSGD(t, 0, 2, uid)  # 3 partitions cannot be dealt to 2 ranks
         with pytest.raises(mf.MfsgdError):
             NativeDSGD(t, 2, 1, uid)  # rank out of range
+
+
+# ---- the persistent epoch kernel when its workgroups cannot all be resident ---------------------------
+def test_persistent_kernel_not_resident_falls_back_to_round_launches(mf, oracle):
+    """A foreign kernel holds every CU's LDS while training is launched: the epoch kernel's residency
+    check gives up before touching anything, the library re-runs the epochs as one launch per round,
+    and the factors still equal the oracle's bit for bit (no 'results invalid')."""
+    rng = np.random.default_rng(88)
+    U, I, k, n, epochs = 2000, 1500, 64, 120000, 3
+    key = rng.choice(U * I, n, replace=False)
+    u, i, r = (key // I).astype(np.int32), (key % I).astype(np.int32), (rng.random(n) * 4 + 1).astype(np.float32)
+    for with_rmse in (False, True):
+        with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 4, blocks=64, waves=2) as m:
+            m.set_ratings(u, i, r)
+            m.init_factors(4)
+            m.rmse()  # everything on the device, nothing in flight
+            m.debug_occupy(600)  # 0.6 s: longer than the residency check waits
+            rm = m.fit(epochs, rmse=with_rmse)
+            P, Q = m.get_factors()
+            order, _ = m.order()
+            rm_after = m.fit(1)  # and the handle keeps working (round launches from now on)
+            P2, Q2 = m.get_factors()
+        Po, Qo, rmo = _oracle_train(oracle, U, I, k, u, i, r, order, 4, epochs)
+        assert np.array_equal(P, Po) and np.array_equal(Q, Qo)
+        if with_rmse:
+            np.testing.assert_allclose(rm, rmo, rtol=1e-9)
+        oracle.sgd_pass_ordered(Po, Qo, u, i, r, order, LR, LAM)
+        assert np.array_equal(P2, Po) and np.array_equal(Q2, Qo)
+        assert abs(rm_after[0] - oracle.rmse(Po, Qo, u, i, r)) <= 1e-9
