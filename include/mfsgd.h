@@ -203,6 +203,11 @@ int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cell
  * own rows; word 7 unused.  out must hold blocks x 8 words.  It DOES apply the epoch.           */
 int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgroups);
 
+/* Diagnostic: out4 = {times a persistent launch found its workgroups not co-resident and the library
+ * switched that partition to round launches, partitions currently on the persistent kernel, cached
+ * training graphs, 0}.                                                                            */
+int mfsgd_debug_counters(const mfsgd_handle* h, int64_t* out4);
+
 /* Diagnostic (not part of the Java surface): occupies the LDS of all but four CUs for `milliseconds` (<= 5000)
  * with a spinning kernel on a side stream, asynchronously -- what a foreign kernel sharing the GPU
  * looks like to the persistent epoch kernel.  Tests use it to force the "workgroups not co-resident"

@@ -98,6 +98,7 @@ SIGNATURES = {
     "mfsgd_debug_get_schedule": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mfsgd_debug_epoch_profile": (C.c_int, [_H, C.POINTER(C.c_uint64), _i32p]),
+    "mfsgd_debug_counters": (C.c_int, [_H, _i64p]),
     "mfsgd_debug_occupy": (C.c_int, [_H, C.c_int32]),
     "mfsgd_debug_round_stamps": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     "mfsgd_dsgd_plan": (C.c_int, [_i64p, _i64p, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p]),

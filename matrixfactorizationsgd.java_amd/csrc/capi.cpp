@@ -80,6 +80,7 @@ struct mfsgd_handle {
     int n_cu = 0;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;  // diagnostics only (mfsgd_debug_occupy)
+    int64_t n_not_resident = 0;         // persistent launches that gave up at the residency check
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     mutable std::string err;
 };
@@ -344,7 +345,7 @@ void give_up_persistence(mfsgd_handle* h, Part& p) {
     (void)hipDeviceSynchronize();
     drop_graphs(p);
     p.persistent_np = 0;
-    (void)h;
+    h->n_not_resident++;
 }
 
 // For callers that cannot re-run what was skipped (asynchronous DSGD sub-epochs on caller-owned blocks).
@@ -973,6 +974,17 @@ int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgro
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *n_workgroups = p.persistent_np;
     return check_abort_strict(h, p);
+}
+
+int mfsgd_debug_counters(const mfsgd_handle* h, int64_t* out4) {
+    if (!h || !out4) return MFSGD_ERR_INVALID_ARG;
+    out4[0] = h->n_not_resident;
+    out4[1] = out4[2] = out4[3] = 0;
+    for (const Part& p : h->parts) {
+        out4[1] += p.persistent_np > 0 ? 1 : 0;  // partitions trained by the persistent kernel
+        out4[2] += (int64_t)p.graphs.size();
+    }
+    return MFSGD_OK;
 }
 
 int mfsgd_debug_occupy(mfsgd_handle* h, int32_t milliseconds) {

@@ -230,6 +230,11 @@ class MatrixFactorizationSGD:
         self.last_slowest_cell = out[: n.value * 8].reshape(n.value, 8)[:, 7]  # longest single "ratings" phase per workgroup
         return out[: n.value * 8].reshape(n.value, 8)[:, :7]
 
+    def debug_counters(self):
+        out = np.zeros(4, np.int64)
+        self._check(self._lib.mfsgd_debug_counters(self._handle(), _p(out, C.c_int64)))
+        return dict(not_resident=int(out[0]), persistent_parts=int(out[1]), graphs=int(out[2]))
+
     def debug_occupy(self, milliseconds):
         """Holds every CU's LDS for a while on a side stream (diagnostic; asynchronous)."""
         self._check(self._lib.mfsgd_debug_occupy(self._handle(), int(milliseconds)))

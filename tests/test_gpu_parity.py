@@ -683,17 +683,20 @@ def test_persistent_kernel_not_resident_falls_back_to_round_launches(mf, oracle)
         with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 4, blocks=64, waves=2) as m:
             m.set_ratings(u, i, r)
             m.init_factors(4)
-            m.rmse()  # everything on the device, nothing in flight
+            first = m.fit(1)  # a normal persistent epoch first
+            assert m.debug_counters()["persistent_parts"] == 1 and m.debug_counters()["not_resident"] == 0
             m.debug_occupy(600)  # 0.6 s: longer than the residency check waits
             rm = m.fit(epochs, rmse=with_rmse)
+            assert m.debug_counters() == dict(not_resident=1, persistent_parts=0, graphs=1), m.debug_counters()
             P, Q = m.get_factors()
             order, _ = m.order()
             rm_after = m.fit(1)  # and the handle keeps working (round launches from now on)
             P2, Q2 = m.get_factors()
-        Po, Qo, rmo = _oracle_train(oracle, U, I, k, u, i, r, order, 4, epochs)
+        Po, Qo, rmo = _oracle_train(oracle, U, I, k, u, i, r, order, 4, epochs + 1)
         assert np.array_equal(P, Po) and np.array_equal(Q, Qo)
+        assert abs(first[0] - rmo[0]) <= 1e-9
         if with_rmse:
-            np.testing.assert_allclose(rm, rmo, rtol=1e-9)
+            np.testing.assert_allclose(rm, rmo[1:], rtol=1e-9)
         oracle.sgd_pass_ordered(Po, Qo, u, i, r, order, LR, LAM)
         assert np.array_equal(P2, Po) and np.array_equal(Q2, Qo)
         assert abs(rm_after[0] - oracle.rmse(Po, Qo, u, i, r)) <= 1e-9
