@@ -115,7 +115,10 @@ const char* mfsgd_last_error(const mfsgd_handle* h);
  * B x B (user block, item tile) cells per item partition and packs every cell
  * into conflict-free wave steps.  Works without a GPU; with one (and >= 2^20
  * ratings) the streaming passes -- degree histograms, bucket order -- run on it,
- * with identical results.  Replaces any earlier ratings.                      */
+ * with identical results.  Replaces any earlier ratings -- unless they ARE the
+ * earlier ratings: the same triples again (length and a 128-bit hash of every
+ * byte of the three arrays) keep the schedules and their device copies, so a host
+ * may hand train() the same arrays on every call at the cost of one pass over them. */
 int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const float* r,
                       int64_t nnz);
 
@@ -205,7 +208,8 @@ int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgro
 
 /* Diagnostic: out4 = {times a persistent launch found its workgroups not co-resident and the library
  * switched that partition to round launches, partitions currently on the persistent kernel, cached
- * training graphs, 0}.                                                                            */
+ * training graphs, schedule builds: mfsgd_set_ratings calls that did not find the same triples
+ * already in place}.                                                                              */
 int mfsgd_debug_counters(const mfsgd_handle* h, int64_t* out4);
 
 /* Diagnostic (not part of the Java surface): occupies the LDS of all but four CUs for `milliseconds` (<= 5000)

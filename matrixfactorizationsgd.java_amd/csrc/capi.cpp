@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <chrono>
@@ -16,6 +17,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -81,6 +83,10 @@ struct mfsgd_handle {
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;  // diagnostics only (mfsgd_debug_occupy)
     int64_t n_not_resident = 0;         // persistent launches that gave up at the residency check
+    // identity of the rating set the schedules were built from: its length and a 128-bit hash of every
+    // byte of u, i and r -- a repeated mfsgd_set_ratings with the same triples keeps the schedules
+    uint64_t ratings_hash[2] = {0, 0};
+    int64_t n_schedule_builds = 0, n_schedule_reuses = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     mutable std::string err;
 };
@@ -411,6 +417,67 @@ int prepare_compute(mfsgd_handle* h) {
     return MFSGD_OK;
 }
 
+// 2 x 64-bit multiply-xorshift hash of the three rating arrays (every byte; the array boundaries and
+// the length are mixed in), computed in parallel over fixed 1 MiB pieces so that it does not depend on
+// the thread count.  Not cryptographic; 128 bits make an accidental match of two different rating sets
+// (the only thing it guards against) a non-event.
+void hash_ratings(const int32_t* u, const int32_t* i, const float* r, int64_t n, int threads, uint64_t out[2]) {
+    constexpr uint64_t M1 = 0x9E3779B97F4A7C15ull, M2 = 0xC2B2AE3D27D4EB4Full;
+    constexpr int64_t kPiece = 1 << 18;  // elements per piece
+    const int64_t pieces = (n + kPiece - 1) / kPiece;
+    std::vector<uint64_t> ph((size_t)pieces * 6, 0);
+    auto piece_hash = [&](const void* base, int64_t lo, int64_t hi, uint64_t& a, uint64_t& b) {
+        const unsigned char* p = static_cast<const unsigned char*>(base) + lo * 4;
+        const int64_t bytes = (hi - lo) * 4;
+        uint64_t h1 = 0x243F6A8885A308D3ull ^ (uint64_t)bytes, h2 = 0x13198A2E03707344ull + (uint64_t)bytes;
+        int64_t x = 0;
+        for (; x + 8 <= bytes; x += 8) {
+            uint64_t w;
+            std::memcpy(&w, p + x, 8);
+            h1 = (h1 ^ w) * M1;
+            h1 ^= h1 >> 32;
+            h2 = (h2 + w) * M2;
+            h2 ^= h2 >> 29;
+        }
+        if (x < bytes) {
+            uint64_t w = 0;
+            std::memcpy(&w, p + x, (size_t)(bytes - x));
+            h1 = (h1 ^ w) * M1;
+            h1 ^= h1 >> 32;
+            h2 = (h2 + w) * M2;
+            h2 ^= h2 >> 29;
+        }
+        a = h1;
+        b = h2;
+    };
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int64_t c = next.fetch_add(1);
+            if (c >= pieces) break;
+            const int64_t lo = c * kPiece, hi = std::min(n, lo + kPiece);
+            piece_hash(u, lo, hi, ph[(size_t)c * 6 + 0], ph[(size_t)c * 6 + 1]);
+            piece_hash(i, lo, hi, ph[(size_t)c * 6 + 2], ph[(size_t)c * 6 + 3]);
+            piece_hash(r, lo, hi, ph[(size_t)c * 6 + 4], ph[(size_t)c * 6 + 5]);
+        }
+    };
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(nt, 64), pieces));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    uint64_t h1 = 0x452821E638D01377ull ^ (uint64_t)n, h2 = 0xBE5466CF34E90C6Cull + (uint64_t)n;
+    for (size_t x = 0; x < ph.size(); x += 2) {
+        h1 = (h1 ^ ph[x]) * M1;
+        h1 ^= h1 >> 32;
+        h2 = (h2 + ph[x + 1]) * M2;
+        h2 ^= h2 >> 29;
+    }
+    out[0] = h1;
+    out[1] = h2;
+}
+
 void fill_rows(JRandom& g, float* dst, int64_t rows, int k, int kp, float scale) {
     for (int64_t x = 0; x < rows; ++x) {
         float* row = dst + x * kp;
@@ -520,6 +587,15 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
         t_last = now;
     };
     try {
+        // The same triples again (Java / C++ / Python hosts hand train() the same arrays every call): keep
+        // the schedules and their device copies.  Exact: length + 128-bit hash of every byte.
+        uint64_t hash[2];
+        hash_ratings(u, i, r, nnz, h->cfg.host_threads, hash);
+        if (h->have_ratings && h->nnz_total == nnz && hash[0] == h->ratings_hash[0] && hash[1] == h->ratings_hash[1]) {
+            h->n_schedule_reuses++;
+            return MFSGD_OK;
+        }
+        lap("hash of the triples");
         // drop what an earlier call built (device copies included)
         if (h->device_ready) {
             (void)hipSetDevice(h->cfg.device);
@@ -635,6 +711,9 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
         }
         lap("schedules");
         h->nnz_total = nnz;
+        h->ratings_hash[0] = hash[0];
+        h->ratings_hash[1] = hash[1];
+        h->n_schedule_builds++;
         h->have_ratings = true;
         return MFSGD_OK;
     } catch (const std::bad_alloc&) {
@@ -979,7 +1058,8 @@ int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgro
 int mfsgd_debug_counters(const mfsgd_handle* h, int64_t* out4) {
     if (!h || !out4) return MFSGD_ERR_INVALID_ARG;
     out4[0] = h->n_not_resident;
-    out4[1] = out4[2] = out4[3] = 0;
+    out4[1] = out4[2] = 0;
+    out4[3] = h->n_schedule_builds;
     for (const Part& p : h->parts) {
         out4[1] += p.persistent_np > 0 ? 1 : 0;  // partitions trained by the persistent kernel
         out4[2] += (int64_t)p.graphs.size();

@@ -30,6 +30,9 @@ public final class MatrixFactorizationSGD implements AutoCloseable {
     /** Runs {@code epochs} SGD passes over the ratings; returns the RMSE after each epoch. */
     public double[] train(int[] u, int[] i, float[] r, int epochs) {
         if (u.length != i.length || u.length != r.length) throw new IllegalArgumentException("length mismatch");
+        // The library recognises the same triples again (length + a 128-bit hash of every byte) and keeps
+        // its schedules, so repeated train() calls on one rating set pay for one pass over the arrays, not
+        // for a new schedule.  (Comparing array identity here would miss in-place edits of the arrays.)
         nativeSetRatings(handle, u, i, r);
         if (!initialised) {
             nativeInitFactors(handle, seed); // java.util.Random(seed).nextFloat()/sqrt(k), P then Q

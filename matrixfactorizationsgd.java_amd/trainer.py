@@ -8,7 +8,6 @@ the surface is the one SURVEY.md section 8b derives from BASELINE.json:
 ``close()``.  Every method is a thin call into the C-ABI (include/mfsgd.h).
 """
 import ctypes as C
-import zlib
 
 import numpy as np
 
@@ -63,7 +62,6 @@ class MatrixFactorizationSGD:
         if rc != 0:
             raise MfsgdError(rc, self._lib.mfsgd_last_error(None).decode())
         self.n_parts = max(1, int(n_parts))
-        self._ratings_key = None
         self._initialised = False
 
     # -- plumbing ---------------------------------------------------------------
@@ -98,17 +96,10 @@ class MatrixFactorizationSGD:
         u, i, r = _i32(u), _i32(i), _f32(r)
         if not (u.shape == i.shape == r.shape and u.ndim == 1):
             raise ValueError("u, i, r must be 1-d arrays of equal length")
-        # cheap fingerprint (a repeated train() on the same arrays must not rebuild the schedule):
-        # length + crc of a strided sample and of both ends; hashing everything costs 0.25 s at 20 M
-        def fp(a):
-            return zlib.crc32(a[::257].tobytes()) ^ zlib.crc32(a[:65536].tobytes()) ^ zlib.crc32(a[-65536:].tobytes())
-
-        key = (u.size, fp(u), fp(i), fp(r))
-        if key == self._ratings_key:
-            return
+        # the library itself recognises the same triples again (exact: every byte is hashed) and keeps the
+        # schedules, so there is nothing to remember here
         self._check(self._lib.mfsgd_set_ratings(self._handle(), _p(u, C.c_int32), _p(i, C.c_int32),
                                                 _p(r, C.c_float), u.size))
-        self._ratings_key = key
 
     def init_factors(self, seed=None):
         self._check(self._lib.mfsgd_init_factors(self._handle(), self.seed if seed is None else int(seed)))
@@ -233,7 +224,7 @@ class MatrixFactorizationSGD:
     def debug_counters(self):
         out = np.zeros(4, np.int64)
         self._check(self._lib.mfsgd_debug_counters(self._handle(), _p(out, C.c_int64)))
-        return dict(not_resident=int(out[0]), persistent_parts=int(out[1]), graphs=int(out[2]))
+        return dict(not_resident=int(out[0]), persistent_parts=int(out[1]), graphs=int(out[2]), schedule_builds=int(out[3]))
 
     def debug_occupy(self, milliseconds):
         """Holds every CU's LDS for a while on a side stream (diagnostic; asynchronous)."""

@@ -113,3 +113,61 @@ def test_product_does_not_reference_the_oracle():
             if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".h", ".java", "Makefile")):
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "mfsgd_oracle" not in txt and "oracle_bind" not in txt and "mfo_" not in txt, fn
+
+
+def test_same_ratings_are_recognised_exactly(mf):
+    """mfsgd_set_ratings keeps the schedules when it is handed the same triples again -- decided on
+    every byte (round 1's Python-side sampled fingerprint missed a change in the middle of the
+    arrays) -- and rebuilds them for any change, wherever it is."""
+    rng = np.random.default_rng(1)
+    n = 300_000
+    U, I = 5000, 4000
+    u = rng.integers(0, U, n).astype(np.int32)
+    i = rng.integers(0, I, n).astype(np.int32)
+    r = rng.random(n).astype(np.float32)
+    with mf.MatrixFactorizationSGD(U, I, 16, 0.01, 0.05, 1) as m:
+        m.set_ratings(u, i, r)
+        o0 = m.order()[0].copy()
+        assert m.debug_counters()["schedule_builds"] == 1
+        m.set_ratings(u.copy(), i.copy(), r.copy())  # other buffers, same triples
+        assert m.debug_counters()["schedule_builds"] == 1
+        for arr, pos, val in ((r, 100_000, 9.0), (u, 150_001, (int(u[150_001]) + 1) % U), (i, n - 1, (int(i[n - 1]) + 1) % I),
+                              (r, 0, -1.0)):
+            arr[pos] = val
+            before = m.debug_counters()["schedule_builds"]
+            m.set_ratings(u, i, r)
+            assert m.debug_counters()["schedule_builds"] == before + 1, (pos, "a changed triple must rebuild the schedule")
+        cells, rows, subs, entries = m.debug_schedule()
+        # the rebuilt schedule carries the NEW rating values
+        got = np.sort(entries[:, 1].view(np.float32))
+        assert got[0] == -1.0 and got[-1] == 9.0
+        m.set_ratings(u[:-1], i[:-1], r[:-1])  # a prefix is a different set
+        assert m.schedule_info()["nnz"] == n - 1
+        assert o0.size == n
+
+
+def test_jni_shim_is_well_formed_cpp():
+    """No JDK exists here, so jni/mfsgd_jni.cpp cannot be built or run; it is at least checked for
+    syntax and types against a declaration-only stub of the JNI signatures it uses
+    (tests/jni_stub/jni.h).  UNTESTED UNDER A JVM all the same."""
+    import shutil
+    import subprocess
+
+    cxx = shutil.which("g++") or shutil.which("c++")
+    assert cxx, "no C++ compiler"
+    p = subprocess.run([cxx, "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
+                        "-I" + os.path.join(ROOT, "tests", "jni_stub"), "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "matrixfactorizationsgd.java_amd", "jni", "mfsgd_jni.cpp")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    src = open(os.path.join(ROOT, "matrixfactorizationsgd.java_amd", "jni", "mfsgd_jni.cpp")).read()
+    # the rule the shim states: nothing pinned around a call that can launch a kernel or wait for the device
+    for fn in ("nativeSetRatings", "nativeTrain", "nativePredict", "nativeRecommend", "nativeGetFactors"):
+        body = src[src.index("Java_MatrixFactorizationSGD_" + fn):]
+        body = body[:body.index("\nJNIEXPORT") if "\nJNIEXPORT" in body else len(body)]
+        assert "Pinned<" not in body and "GetPrimitiveArrayCritical" not in body, fn
+    # every native method the Java class declares has its JNI function, and vice versa
+    java = open(os.path.join(ROOT, "matrixfactorizationsgd.java_amd", "java", "MatrixFactorizationSGD.java")).read()
+    declared = set(re.findall(r"private static native \S+ (native\w+)\(", java))
+    defined = set(re.findall(r"Java_MatrixFactorizationSGD_(native\w+)\(", src))
+    assert declared == defined and len(declared) >= 10

@@ -687,7 +687,8 @@ def test_persistent_kernel_not_resident_falls_back_to_round_launches(mf, oracle)
             assert m.debug_counters()["persistent_parts"] == 1 and m.debug_counters()["not_resident"] == 0
             m.debug_occupy(600)  # 0.6 s: longer than the residency check waits
             rm = m.fit(epochs, rmse=with_rmse)
-            assert m.debug_counters() == dict(not_resident=1, persistent_parts=0, graphs=1), m.debug_counters()
+            c = m.debug_counters()
+            assert (c["not_resident"], c["persistent_parts"], c["graphs"]) == (1, 0, 1), c
             P, Q = m.get_factors()
             order, _ = m.order()
             rm_after = m.fit(1)  # and the handle keeps working (round launches from now on)
@@ -700,3 +701,59 @@ def test_persistent_kernel_not_resident_falls_back_to_round_launches(mf, oracle)
         oracle.sgd_pass_ordered(Po, Qo, u, i, r, order, LR, LAM)
         assert np.array_equal(P2, Po) and np.array_equal(Q2, Qo)
         assert abs(rm_after[0] - oracle.rmse(Po, Qo, u, i, r)) <= 1e-9
+
+
+# ---- hosts above the C-ABI ---------------------------------------------------------------------------
+def test_train_after_editing_one_rating_in_the_middle(mf, oracle):
+    """train(u, i, r) twice with ONE rating changed in the middle of the arrays in between (round 1's
+    Python-side sampled fingerprint trained on the stale schedule): the second call must see the new
+    value -- factors bit-exact against the oracle run on the edited ratings."""
+    rng = np.random.default_rng(5)
+    U, I, k, n = 3000, 2500, 32, 300_000
+    key = rng.choice(U * I, n, replace=False)
+    u, i, r = (key // I).astype(np.int32), (key % I).astype(np.int32), (rng.random(n) * 4 + 1).astype(np.float32)
+    with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 6) as m:
+        m.train(u, i, r, 1)
+        order1, _ = m.order()
+        m.train(u, i, r, 1)  # same triples: the schedule is kept
+        assert m.debug_counters()["schedule_builds"] == 1
+        r0 = r.copy()
+        r[100_000] = 9.0
+        m.train(u, i, r, 1)
+        assert m.debug_counters()["schedule_builds"] == 2
+        order2, _ = m.order()
+        P, Q = m.get_factors()
+    Po, Qo = oracle.init_factors(U, I, k, 6)
+    oracle.sgd_pass_ordered(Po, Qo, u, i, r0, order1, LR, LAM)
+    oracle.sgd_pass_ordered(Po, Qo, u, i, r0, order1, LR, LAM)
+    oracle.sgd_pass_ordered(Po, Qo, u, i, r, order2, LR, LAM)
+    assert np.array_equal(P, Po) and np.array_equal(Q, Qo)
+
+
+def test_compiled_cpp_host_example(mf, oracle):
+    """lib/mfsgd_example -- the compiled C++ mirror of the Java class (cpp/MatrixFactorizationSGD.hpp,
+    the only compiled stand-in for the Java host) -- in a fresh process: its RMSE lines and its
+    predict() against the oracle on the same ratings, seed and order."""
+    import os
+    import re
+    import subprocess
+
+    from tests.conftest import ROOT
+
+    exe = os.path.join(ROOT, "matrixfactorizationsgd.java_amd", "lib", "mfsgd_example")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout
+    got = [float(x) for x in re.findall(r"epoch \d+ rmse ([0-9.]+)", p.stdout)]
+    pred = float(re.search(r"predict\(3,4\) = ([-0-9.]+)", p.stdout).group(1))
+    U, I, k = 100, 80, 8
+    u = np.repeat(np.arange(U), I).astype(np.int32)
+    i = np.tile(np.arange(I), U).astype(np.int32)
+    r = (1.0 + ((u * 7 + i * 3) % 5)).astype(np.float32)
+    with mf.MatrixFactorizationSGD(U, I, k, 0.01, 0.05, 42) as m:
+        m.set_ratings(u, i, r)
+        order, _ = m.order()
+    Po, Qo, rmo = _oracle_train(oracle, U, I, k, u, i, r, order, 42, 5, 0.01, 0.05)
+    assert len(got) == 5
+    np.testing.assert_allclose(got, rmo, atol=1e-6)  # printed with six decimals
+    assert abs(pred - oracle.predict(Po, Qo, np.array([3], np.int32), np.array([4], np.int32))[0]) <= 1e-6
