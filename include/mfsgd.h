@@ -69,6 +69,7 @@ typedef struct mfsgd_config {
 #define MFSGD_FLAG_NO_GRAPH 1     /* launch eagerly instead of replaying a hipGraph            */
 #define MFSGD_FLAG_HOST_INGEST 4   /* bucket the ratings on the host even when a GPU is present     */
 #define MFSGD_FLAG_DEVICE_INGEST 8 /* ... on the GPU even for small rating sets (default: >= 2^20)  */
+#define MFSGD_FLAG_HOST_PACK 32     /* pack the cells on the host even when the device could (tests: both build the same bytes) */
 #define MFSGD_FLAG_NO_SOLO 16      /* schedule without solo runs (A/B measurements, tests)           */
 #define MFSGD_FLAG_ROUND_LAUNCH 2 /* one kernel launch per round instead of the persistent      */
                                   /* epoch kernel (which hands item tiles between workgroups)   */
@@ -92,7 +93,8 @@ typedef struct mfsgd_schedule_info {
     int64_t sum_round_steps; /* sum over rounds of the slowest cell's critical path */
     double build_seconds;
     int32_t swapped;      /* 1: roles exchanged (users on the kernel's forwarding side): in the   */
-    int32_t device_ingest; /* 1: degree histograms and bucket order were computed on the GPU      */
+    int32_t device_ingest; /* 1: degree histograms and bucket order were computed on the GPU; 2: the cells */
+                           /* were packed there too (rows / entries / order never existed on the host)  */
     int64_t chunks;       /* chunk descriptors (>= blocks*blocks: one per cell + extra chunks)    */
     int64_t split_cells;  /* cells cut into more than one chunk because they exceed the LDS       */
 } mfsgd_schedule_info;

@@ -61,6 +61,7 @@ FLAG_ROUND_LAUNCH = 2
 FLAG_HOST_INGEST = 4
 FLAG_DEVICE_INGEST = 8
 FLAG_NO_SOLO = 16
+FLAG_HOST_PACK = 32
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)

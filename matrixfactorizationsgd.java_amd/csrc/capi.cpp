@@ -206,9 +206,21 @@ int ensure_part_on_device(mfsgd_handle* h, Part& p) {
     if (p.on_device) return MFSGD_OK;
     int rc;
     if ((rc = upload(h, p.d_cells, p.sched.cells))) return rc;
-    if ((rc = upload(h, p.d_rows, p.sched.rows))) return rc;
     if ((rc = upload(h, p.d_subs, p.sched.subs))) return rc;
-    if ((rc = upload(h, p.d_entries, p.sched.entries))) return rc;
+    if (p.sched.device_packed) {
+        // the device packer left rows and entries where they are needed
+        p.d_rows.release();
+        p.d_entries.release();
+        p.d_rows.p = p.sched.dev.buf.rows;
+        p.d_rows.bytes = (size_t)p.sched.n_rows_words * sizeof(uint32_t);
+        p.d_entries.p = p.sched.dev.buf.entries;
+        p.d_entries.bytes = (size_t)p.sched.n_entry_recs * sizeof(Entry);
+        p.sched.dev.buf.rows = nullptr;  // owned by the DevBufs from here on (same allocator: hipFree)
+        p.sched.dev.buf.entries = nullptr;
+    } else {
+        if ((rc = upload(h, p.d_rows, p.sched.rows))) return rc;
+        if ((rc = upload(h, p.d_entries, p.sched.entries))) return rc;
+    }
     if ((rc = dev_alloc(h, p.d_sse_partial, sizeof(double) * p.sched.cells.size()))) return rc;
     if ((rc = dev_alloc(h, p.d_sse_out, sizeof(double)))) return rc;
     if ((rc = dev_alloc(h, p.d_sync, sync_bytes(p)))) return rc;
@@ -406,6 +418,35 @@ int settle_epochs(mfsgd_handle* h, Part& p, float* Q, hipStream_t st, int launch
         if ((rc = launch_epoch(h, p, Q, st))) return rc;
     HIPCHK(h, hipStreamSynchronize(st));
     return MFSGD_OK;
+}
+
+// Host copies of a device-packed schedule's big arrays, made when somebody asks for them
+// (mfsgd_get_order, the debug getters): they never existed on the host.
+int host_copies(const mfsgd_handle* h, const Part& cp, bool want_order, bool want_arrays) {
+    Part& p = const_cast<Part&>(cp);
+    Schedule& s = p.sched;
+    if (!s.device_packed || !s.dev_ops || !s.dev_ops->download) return MFSGD_OK;
+    try {
+        DevicePacked d = s.dev.buf;
+        if (p.on_device) {  // rows / entries have moved into the DevBufs
+            d.rows = p.d_rows.p;
+            d.entries = p.d_entries.p;
+        }
+        if (want_order && s.order.empty() && s.nnz > 0) {
+            s.order.resize_uninit((size_t)s.nnz);
+            if (s.dev_ops->download(d, nullptr, 0, nullptr, 0, s.order.data(), s.nnz) != 0)
+                return fail(h, MFSGD_ERR_HIP, "could not copy the canonical order from the device");
+        }
+        if (want_arrays && s.entries.empty() && s.n_entry_recs > 0) {
+            s.rows.resize_uninit((size_t)s.n_rows_words);
+            s.entries.resize_uninit((size_t)s.n_entry_recs);
+            if (s.dev_ops->download(d, s.rows.data(), s.n_rows_words, s.entries.data(), s.n_entry_recs, nullptr, 0) != 0)
+                return fail(h, MFSGD_ERR_HIP, "could not copy the schedule from the device");
+        }
+        return MFSGD_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(h, MFSGD_ERR_OOM, "out of host memory");
+    }
 }
 
 int prepare_compute(mfsgd_handle* h) {
@@ -644,6 +685,7 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
         prm.W = h->cfg.waves;
         prm.threads = h->cfg.host_threads;
         prm.solo = !(h->cfg.flags & MFSGD_FLAG_NO_SOLO);
+        prm.device_pack = !(h->cfg.flags & MFSGD_FLAG_HOST_PACK);
         if (G == 1) {
             Part& p = h->parts[0];
             p.q_rows = h->cfg.n_items;
@@ -990,7 +1032,7 @@ int mfsgd_get_schedule_info(const mfsgd_handle* h, int32_t part, mfsgd_schedule_
     out->sum_round_steps = s.sum_round_steps;
     out->build_seconds = s.build_seconds;
     out->swapped = h->parts[(size_t)part].swapped ? 1 : 0;
-    out->device_ingest = s.device_ingest ? 1 : 0;
+    out->device_ingest = s.device_packed ? 2 : s.device_ingest ? 1 : 0;
     out->chunks = (int64_t)s.cells.size();
     out->split_cells = s.split_cells;
     return MFSGD_OK;
@@ -1000,6 +1042,10 @@ int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t
     if (!h) return MFSGD_ERR_INVALID_ARG;
     if (!h->have_ratings) return fail(h, MFSGD_ERR_STATE, "get_order: no ratings");
     if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "get_order: bad partition");
+    if (order) {
+        const int rc = host_copies(h, h->parts[(size_t)part], true, false);
+        if (rc) return rc;
+    }
     const Schedule& s = h->parts[(size_t)part].sched;
     if (order && !s.order.empty()) std::memcpy(order, s.order.data(), s.order.size() * sizeof(int64_t));
     if (cell_ptr) std::memcpy(cell_ptr, s.cell_ptr.data(), s.cell_ptr.size() * sizeof(int64_t));
@@ -1013,9 +1059,9 @@ int mfsgd_debug_schedule_sizes(const mfsgd_handle* h, int32_t part, int64_t* n_c
     if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_schedule_sizes: bad partition");
     const Schedule& s = h->parts[(size_t)part].sched;
     *n_cells = (int64_t)s.cells.size();
-    *n_rows = (int64_t)s.rows.size();
+    *n_rows = s.n_rows_words;
     *n_subs = (int64_t)s.subs.size();
-    *n_entries = (int64_t)s.entries.size();
+    *n_entries = s.n_entry_recs;
     return MFSGD_OK;
 }
 
@@ -1024,6 +1070,10 @@ int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cell
     if (!h) return MFSGD_ERR_INVALID_ARG;
     if (!h->have_ratings) return fail(h, MFSGD_ERR_STATE, "debug_get_schedule: no ratings");
     if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_get_schedule: bad partition");
+    if (rows || entries) {
+        const int rc = host_copies(h, h->parts[(size_t)part], false, true);
+        if (rc) return rc;
+    }
     const Schedule& s = h->parts[(size_t)part].sched;
     if (cells && !s.cells.empty()) std::memcpy(cells, s.cells.data(), s.cells.size() * sizeof(CellDesc));
     if (rows && !s.rows.empty()) std::memcpy(rows, s.rows.data(), s.rows.size() * sizeof(uint32_t));

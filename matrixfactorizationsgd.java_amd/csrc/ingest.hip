@@ -3,10 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <algorithm>
 #include <cstdint>
 #include <vector>
 
 #include "ingest.hpp"
+#include "pack.hpp"
 
 namespace mfsgd {
 
@@ -19,6 +21,17 @@ struct Ctx {
     const int32_t* host_i = nullptr;
     int64_t n = 0;
     int32_t *du = nullptr, *di = nullptr;
+    // kept after bucket_dev() for the device packer
+    unsigned* d_sorted = nullptr;    // rating indices in bucket order
+    long long* d_bptr = nullptr;     // nb + 1
+    int64_t nb = 0;
+    float* d_r = nullptr;
+    long long* d_orig = nullptr;
+    int32_t *d_urank = nullptr, *d_irank = nullptr;
+    PackCellInfo* d_info = nullptr;
+    SubDesc* d_subs = nullptr;
+    PackArgs args{};                 // as launched for COUNT; EMIT reuses it
+    int64_t n_cells = 0;
 };
 
 #define ING_CHK(call)                      \
@@ -29,7 +42,21 @@ struct Ctx {
         }                                  \
     } while (0)
 
+void drop_pack_state(Ctx* c) {
+    void* ptrs[] = {c->d_sorted, c->d_bptr, c->d_r, c->d_orig, c->d_urank, c->d_irank, c->d_info, c->d_subs};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    c->d_sorted = nullptr;
+    c->d_bptr = nullptr;
+    c->d_r = nullptr;
+    c->d_orig = nullptr;
+    c->d_urank = c->d_irank = nullptr;
+    c->d_info = nullptr;
+    c->d_subs = nullptr;
+}
+
 void drop_triples(Ctx* c) {
+    drop_pack_state(c);
     if (c->du) (void)hipFree(c->du);
     if (c->di) (void)hipFree(c->di);
     c->du = c->di = nullptr;
@@ -123,19 +150,19 @@ fail:
     return -1;
 }
 
-int bucket_cb(void* vctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
-              int32_t U, int32_t I, int B, int W, int64_t* bptr, int64_t* sorted) {
-    Ctx* c = static_cast<Ctx*>(vctx);
+// Keys, one stable LSD radix sort of (key, index) pairs, bucket starts.  Leaves the sorted indices and
+// the bucket starts on the device (c->d_sorted, c->d_bptr).
+int bucket_on_device(Ctx* c, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
+                     int32_t U, int32_t I, int B, int W) {
     const int64_t nb = (int64_t)B * B * W * W;
     if (n >= (int64_t)1 << 32 || nb >= (int64_t)1 << 32) return -1;
     if (!ensure_triples(c, u, i, n)) return -1;
+    drop_pack_state(c);
     int32_t *d_ubin = nullptr, *d_ibin = nullptr;
     unsigned *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr;
     long long* d_bptr = nullptr;
     void* temp = nullptr;
     size_t temp_bytes = 0;
-    std::vector<unsigned> hv;
-    std::vector<long long> hb;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     unsigned bits = 1;
     while (((int64_t)1 << bits) < nb) ++bits;
@@ -156,14 +183,11 @@ int bucket_cb(void* vctx, const int32_t* u, const int32_t* i, int64_t n, const i
     ING_CHK(rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, (size_t)n, 0u, bits, (hipStream_t)0));
     hipLaunchKernelGGL(bound_kernel, dim3(grid_for(nb + 1)), dim3(256), 0, 0, k1, n, nb, d_bptr);
     ING_CHK(hipGetLastError());
-    hv.resize(nn);
-    hb.resize((size_t)(nb + 1));
-    ING_CHK(hipMemcpy(hv.data(), v1, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    ING_CHK(hipMemcpy(hb.data(), d_bptr, sizeof(long long) * (size_t)(nb + 1), hipMemcpyDeviceToHost));
-    for (int64_t j = 0; j < n; ++j) sorted[j] = (int64_t)hv[(size_t)j];
-    for (int64_t b = 0; b <= nb; ++b) bptr[b] = (int64_t)hb[(size_t)b];
-    (void)hipFree(d_ubin); (void)hipFree(d_ibin); (void)hipFree(k0); (void)hipFree(k1); (void)hipFree(v0); (void)hipFree(v1);
-    (void)hipFree(d_bptr); (void)hipFree(temp);
+    ING_CHK(hipDeviceSynchronize());
+    (void)hipFree(d_ubin); (void)hipFree(d_ibin); (void)hipFree(k0); (void)hipFree(k1); (void)hipFree(v0); (void)hipFree(temp);
+    c->d_sorted = v1;
+    c->d_bptr = d_bptr;
+    c->nb = nb;
     return 0;
 fail:
     if (d_ubin) (void)hipFree(d_ubin);
@@ -177,6 +201,178 @@ fail:
     return -1;
 }
 
+int fetch_bptr(Ctx* c, int64_t* bptr) {
+    std::vector<long long> hb((size_t)(c->nb + 1));
+    if (hipMemcpy(hb.data(), c->d_bptr, sizeof(long long) * hb.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    for (int64_t b = 0; b <= c->nb; ++b) bptr[b] = (int64_t)hb[(size_t)b];
+    return 0;
+}
+
+int fetch_sorted_cb(void* vctx, int64_t* sorted) {
+    Ctx* c = static_cast<Ctx*>(vctx);
+    if (!c->d_sorted) return -1;
+    std::vector<unsigned> hv((size_t)(c->n > 0 ? c->n : 1));
+    if (hipMemcpy(hv.data(), c->d_sorted, 4 * (size_t)c->n, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    for (int64_t j = 0; j < c->n; ++j) sorted[j] = (int64_t)hv[(size_t)j];
+    return 0;
+}
+
+int bucket_dev_cb(void* vctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
+                  int32_t U, int32_t I, int B, int W, int64_t* bptr) {
+    Ctx* c = static_cast<Ctx*>(vctx);
+    if (bucket_on_device(c, u, i, n, ubin, ibin, U, I, B, W) != 0) return -1;
+    return fetch_bptr(c, bptr);
+}
+
+int bucket_cb(void* vctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
+              int32_t U, int32_t I, int B, int W, int64_t* bptr, int64_t* sorted) {
+    Ctx* c = static_cast<Ctx*>(vctx);
+    if (bucket_on_device(c, u, i, n, ubin, ibin, U, I, B, W) != 0) return -1;
+    const int rc = fetch_bptr(c, bptr) == 0 && fetch_sorted_cb(c, sorted) == 0 ? 0 : -1;
+    drop_pack_state(c);
+    return rc;
+}
+
+// ---- the device packer (pack.hip) behind the DeviceIngestExt callbacks ----------------------------
+void release_cb(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+// rank of every row among the rows of its block (block = bin % B), ascending row index
+void block_ranks(const int32_t* bin, int32_t n, int B, std::vector<int32_t>& rank, int32_t& max_rank) {
+    std::vector<int32_t> next((size_t)B, 0);
+    rank.resize((size_t)n);
+    for (int32_t x = 0; x < n; ++x) rank[(size_t)x] = next[(size_t)(bin[x] % B)]++;
+    max_rank = 0;
+    for (int b = 0; b < B; ++b) max_rank = std::max(max_rank, next[(size_t)b]);
+}
+
+int pack_count_cb(void* vctx, const PackRequest& q, std::vector<PackCellInfo>& info, std::vector<SubDesc>& subs) {
+    Ctx* c = static_cast<Ctx*>(vctx);
+    if (!c->d_sorted || !c->d_bptr || c->host_u != q.u || c->host_i != q.i || c->n != q.n) return -1;
+    const int64_t n_cells = (int64_t)q.B * q.B, WW = (int64_t)q.W * q.W;
+    if (n_cells >= (int64_t)1 << 31 || q.G > 64) return 1;
+    std::vector<int32_t> ur, ir;
+    int32_t mu = 0, mi = 0;
+    block_ranks(q.ubin, q.U, q.B, ur, mu);
+    block_ranks(q.ibin, q.I, q.B, ir, mi);
+    PackArgs a{};
+    a.max_m = (int)((std::max<int64_t>(q.max_cell_nnz, 64) + 63) / 64 * 64);
+    if (mu > 65535 || mi > 65535 || a.max_m > 2048) return 1;  // 16-bit ranks, 32 candidates per lane
+    a.u_words = (mu + 31) / 32 + 1;
+    a.i_words = (mi + 31) / 32 + 1;
+    // rows a cell can touch: at most 2 per rating and at most what the blocks hold; the training kernel's LDS
+    // image (160 KiB) cannot hold more than 10240 16-byte units of rows anyway
+    a.max_rows = (int)std::min<int64_t>(std::min<int64_t>(2 * (int64_t)a.max_m, (int64_t)mu + mi), 32767 / std::max(1, q.L));
+    a.max_rows = std::max(a.max_rows, 8);
+    a.B = q.B;
+    a.W = q.W;
+    a.G = q.G;
+    a.L = q.L;
+    a.lr = q.lr;
+    a.c = q.c;
+    a.solo_ok = q.solo_ok ? 1 : 0;
+    if (pack_lds_bytes(a) > 160 * 1024 - 256) return 1;
+    int rc = -1;
+    ING_CHK(hipMalloc(&c->d_r, sizeof(float) * (size_t)std::max<int64_t>(q.n, 1)));
+    ING_CHK(hipMemcpy(c->d_r, q.r, sizeof(float) * (size_t)q.n, hipMemcpyHostToDevice));
+    if (q.orig) {
+        ING_CHK(hipMalloc(&c->d_orig, sizeof(long long) * (size_t)std::max<int64_t>(q.n, 1)));
+        ING_CHK(hipMemcpy(c->d_orig, q.orig, sizeof(long long) * (size_t)q.n, hipMemcpyHostToDevice));
+    }
+    ING_CHK(hipMalloc(&c->d_urank, sizeof(int32_t) * (size_t)q.U));
+    ING_CHK(hipMalloc(&c->d_irank, sizeof(int32_t) * (size_t)q.I));
+    ING_CHK(hipMemcpy(c->d_urank, ur.data(), sizeof(int32_t) * (size_t)q.U, hipMemcpyHostToDevice));
+    ING_CHK(hipMemcpy(c->d_irank, ir.data(), sizeof(int32_t) * (size_t)q.I, hipMemcpyHostToDevice));
+    ING_CHK(hipMalloc(&c->d_info, sizeof(PackCellInfo) * (size_t)n_cells));
+    ING_CHK(hipMalloc(&c->d_subs, sizeof(SubDesc) * (size_t)(n_cells * WW)));
+    a.u = c->du;
+    a.i = c->di;
+    a.r = c->d_r;
+    a.orig = c->d_orig;
+    a.sorted = c->d_sorted;
+    a.bptr = c->d_bptr;
+    a.urank = c->d_urank;
+    a.irank = c->d_irank;
+    a.info = c->d_info;
+    a.subs = c->d_subs;
+    a.emit = 0;
+    ING_CHK(launch_pack(a, n_cells, (hipStream_t)0));
+    info.resize((size_t)n_cells);
+    subs.resize((size_t)(n_cells * WW));
+    ING_CHK(hipMemcpy(info.data(), c->d_info, sizeof(PackCellInfo) * (size_t)n_cells, hipMemcpyDeviceToHost));
+    ING_CHK(hipMemcpy(subs.data(), c->d_subs, sizeof(SubDesc) * (size_t)(n_cells * WW), hipMemcpyDeviceToHost));
+    c->args = a;
+    c->n_cells = n_cells;
+    return 0;
+fail:
+    return rc;
+}
+
+int pack_emit_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
+                 int64_t n_steps, DevicePacked* out) {
+    Ctx* c = static_cast<Ctx*>(vctx);
+    if (!c->d_info || !out) return -1;
+    PackArgs a = c->args;
+    uint32_t *d_ro = nullptr, *d_eo = nullptr, *d_rows = nullptr;
+    long long *d_oo = nullptr, *d_order = nullptr;
+    Entry* d_ent = nullptr;
+    const size_t nc = (size_t)c->n_cells;
+    std::vector<long long> oo(ord_off, ord_off + nc);
+    ING_CHK(hipMalloc(&d_ro, 4 * nc));
+    ING_CHK(hipMalloc(&d_eo, 4 * nc));
+    ING_CHK(hipMalloc(&d_oo, 8 * nc));
+    ING_CHK(hipMemcpy(d_ro, row_off, 4 * nc, hipMemcpyHostToDevice));
+    ING_CHK(hipMemcpy(d_eo, ent_off, 4 * nc, hipMemcpyHostToDevice));
+    ING_CHK(hipMemcpy(d_oo, oo.data(), 8 * nc, hipMemcpyHostToDevice));
+    ING_CHK(hipMalloc(&d_rows, 4 * (size_t)(n_rows + 4)));
+    ING_CHK(hipMemset(d_rows + n_rows, 0, 16));  // the staging DMA reads whole 16-byte units
+    ING_CHK(hipMalloc(&d_ent, sizeof(Entry) * (size_t)std::max<int64_t>(n_steps * a.G, 1)));
+    ING_CHK(hipMalloc(&d_order, 8 * (size_t)std::max<int64_t>(c->n, 1)));
+    a.emit = 1;
+    a.row_off = d_ro;
+    a.ent_off = d_eo;
+    a.ord_off = d_oo;
+    a.rows = d_rows;
+    a.entries = d_ent;
+    a.order = d_order;
+    ING_CHK(launch_pack(a, c->n_cells, (hipStream_t)0));
+    ING_CHK(hipDeviceSynchronize());
+    (void)hipFree(d_ro); (void)hipFree(d_eo); (void)hipFree(d_oo);
+    out->rows = d_rows;
+    out->entries = d_ent;
+    out->order = d_order;
+    out->release = release_cb;
+    drop_pack_state(c);
+    return 0;
+fail:
+    if (d_ro) (void)hipFree(d_ro);
+    if (d_eo) (void)hipFree(d_eo);
+    if (d_oo) (void)hipFree(d_oo);
+    if (d_rows) (void)hipFree(d_rows);
+    if (d_ent) (void)hipFree(d_ent);
+    if (d_order) (void)hipFree(d_order);
+    return -1;
+}
+
+int download_cb(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* entries, int64_t n_entries, int64_t* order,
+                int64_t n) {
+    if (rows && n_rows > 0 && hipMemcpy(rows, d.rows, 4 * (size_t)n_rows, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (entries && n_entries > 0 &&
+        hipMemcpy(entries, d.entries, sizeof(Entry) * (size_t)n_entries, hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    if (order && n > 0 && hipMemcpy(order, d.order, 8 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return 0;
+}
+
+const DeviceIngestExt kExt = {bucket_dev_cb, fetch_sorted_cb, pack_count_cb, pack_emit_cb, download_cb};
+
 }  // namespace
 
 DeviceIngest make_device_ingest(int device) {
@@ -186,6 +382,7 @@ DeviceIngest make_device_ingest(int device) {
     d.ctx = c;
     d.degrees = degrees_cb;
     d.bucket = bucket_cb;
+    d.ext = &kExt;
     return d;
 }
 

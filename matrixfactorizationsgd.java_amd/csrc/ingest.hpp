@@ -5,6 +5,9 @@
 #pragma once
 
 #include <cstdint>
+#include <vector>
+
+#include "records.hpp"
 
 namespace mfsgd {
 
@@ -20,6 +23,47 @@ struct DeviceIngest {
     // input order).  Returns 0 on success.
     int (*bucket)(void* ctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
                   int32_t U, int32_t I, int B, int W, int64_t* bptr, int64_t* sorted) = nullptr;
+    const struct DeviceIngestExt* ext = nullptr;  // the device packer, when available
+};
+
+// ---- second phase: the per-cell step packer on the device (pack.hip) ------------------------------
+struct PackRequest {
+    const int32_t* u = nullptr;     // host arrays handed to degrees() / bucket_dev() (identity check)
+    const int32_t* i = nullptr;
+    const float* r = nullptr;       // host: ratings
+    const int64_t* orig = nullptr;  // host or null: caller-visible rating indices
+    int64_t n = 0;
+    int32_t U = 0, I = 0;
+    const int32_t* ubin = nullptr;  // host: fine bin of every P row / Q row (block = bin % B)
+    const int32_t* ibin = nullptr;
+    int B = 0, W = 0, G = 0, L = 0;
+    float lr = 0.f, c = 0.f;
+    bool solo_ok = false;
+    int64_t max_cell_nnz = 0;       // from bptr
+};
+// Buffers a successful emit() leaves on the device; the receiver frees them with `release`.
+struct DevicePacked {
+    void* rows = nullptr;     // uint32 x n_rows (+4 padding words)
+    void* entries = nullptr;  // Entry x n_entries
+    void* order = nullptr;    // int64 x n
+    void (*release)(void*) = nullptr;
+};
+
+struct DeviceIngestExt {
+    // like DeviceIngest::bucket, but the sorted indices stay on the device (only bptr comes back)
+    int (*bucket_dev)(void* ctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
+                      int32_t U, int32_t I, int B, int W, int64_t* bptr) = nullptr;
+    // the sorted indices after bucket_dev, for the host packer (fallback)
+    int (*fetch_sorted)(void* ctx, int64_t* sorted) = nullptr;
+    // COUNT pass: 0 = done (info: B*B, subs: B*B*W*W), 1 = this rating set is outside what the kernel
+    // handles (nothing produced), -1 = a HIP call failed
+    int (*pack_count)(void* ctx, const PackRequest& req, std::vector<PackCellInfo>& info, std::vector<SubDesc>& subs) = nullptr;
+    // EMIT pass at the offsets the caller derived from the COUNT pass (per cell, B*B entries each)
+    int (*pack_emit)(void* ctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
+                     int64_t n_steps, DevicePacked* out) = nullptr;
+    // device -> host copies of what emit() produced (debug / get_order); any pointer may be null
+    int (*download)(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* entries, int64_t n_entries, int64_t* order,
+                    int64_t n) = nullptr;
 };
 
 // Implemented in ingest.hip.  `device` must already be usable (capi checks).

@@ -96,8 +96,6 @@ struct Scratch {
     std::vector<std::pair<int32_t, uint16_t>> top;
 };
 
-constexpr int kRunMin = 8;  // shortest item chain worth a register-resident run
-constexpr int kSoloMin = 12;  // shortest chain worth a solo run (a second wave does the off-chain half)
 
 // Packs the ratings rs[0..n) of one sub-cell into steps of G conflict-free
 // slots.  `t0` is the running step stamp of the cell (unique per step).
@@ -411,11 +409,23 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         const int s = (is - us + W) % W;
         return (((int64_t)ub * B + it) * W + s) * W + us;
     };
-    std::vector<int64_t> sorted((size_t)n);
-    if (on_device && prm.ingest->bucket(prm.ingest->ctx, u, i, n, ubin.data(), ibin.data(), U, I, B, W, bptr.data(),
-                                        sorted.data()) != 0) {
-        on_device = false;
-        std::fill(bptr.begin(), bptr.end(), 0);
+    std::vector<int64_t> sorted;
+    const DeviceIngestExt* ext = (on_device && prm.device_pack && prm.ingest->ext && prm.ingest->ext->bucket_dev &&
+                                  prm.ingest->ext->pack_count && prm.ingest->ext->pack_emit && n > 0)
+                                     ? prm.ingest->ext
+                                     : nullptr;
+    bool sorted_on_device = false;
+    if (ext && ext->bucket_dev(prm.ingest->ctx, u, i, n, ubin.data(), ibin.data(), U, I, B, W, bptr.data()) == 0)
+        sorted_on_device = true;
+    else
+        ext = nullptr;
+    if (!sorted_on_device) {
+        sorted.resize((size_t)n);
+        if (on_device && prm.ingest->bucket(prm.ingest->ctx, u, i, n, ubin.data(), ibin.data(), U, I, B, W, bptr.data(),
+                                            sorted.data()) != 0) {
+            on_device = false;
+            std::fill(bptr.begin(), bptr.end(), 0);
+        }
     }
     if (!on_device) {
         std::vector<int64_t> bkt((size_t)n);
@@ -439,9 +449,125 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     const bool solo_ok = prm.solo && geo.L >= 16 && W <= 4;
     const int64_t avail = (int64_t)prm.lds_budget - 16;
     const int64_t min_sched = sched_bytes_for(geo, W, 2, 3), min_rows = rows_bytes_for(geo, 2);
+    auto addressable = [&](int nrows) { return (int64_t)(nrows + 2 * G) * geo.L <= 32767; };
     if (avail < 2 * min_sched + min_rows) {
         err = "lds: the LDS budget cannot hold a single rating at this k";
         return -1;
+    }
+    // ---- the device packer: every cell as a single chunk, same bytes as the host packer below -----
+    if (sorted_on_device) {
+        const int rc = [&]() -> int {
+            PackRequest q;
+            q.u = u;
+            q.i = i;
+            q.r = r;
+            q.orig = orig;
+            q.n = n;
+            q.U = U;
+            q.I = I;
+            q.ubin = ubin.data();
+            q.ibin = ibin.data();
+            q.B = B;
+            q.W = W;
+            q.G = G;
+            q.L = geo.L;
+            q.lr = hy.lr;
+            q.c = hy.c;
+            q.solo_ok = solo_ok;
+            for (int64_t cc = 0; cc < ncell; ++cc)
+                q.max_cell_nnz = std::max(q.max_cell_nnz, bptr[(size_t)((cc + 1) * WW)] - bptr[(size_t)(cc * WW)]);
+            std::vector<PackCellInfo> info;
+            std::vector<SubDesc> dsubs;
+            int prc = ext->pack_count(prm.ingest->ctx, q, info, dsubs);
+            if (prc != 0) return prc;
+            lap("  device pack: count");
+            // every cell must fit the training kernel's LDS image as ONE chunk (chunking is the host's job)
+            int64_t max_s = min_sched, max_r = min_rows, tot_rows = 0, tot_steps = 0;
+            std::vector<uint32_t> row_off((size_t)ncell), ent_off((size_t)ncell);
+            for (int64_t cc = 0; cc < ncell; ++cc) {
+                const PackCellInfo& ci = info[(size_t)cc];
+                if (ci.status != 0) return 1;
+                const int nrows = (int)(ci.nu + ci.ni);
+                if (ci.n_steps != 0) {
+                    if (!addressable(nrows) || rows_bytes_for(geo, nrows) + 2 * min_sched > avail) return 1;
+                    max_s = std::max(max_s, sched_bytes_for(geo, W, nrows, (int64_t)ci.n_steps));
+                    max_r = std::max(max_r, rows_bytes_for(geo, nrows));
+                }
+                if (tot_rows > 0xFFFFFFFFll - nrows || tot_steps > 0xFFFFFFFFll - (int64_t)ci.n_steps) return 1;
+                row_off[(size_t)cc] = (uint32_t)tot_rows;
+                ent_off[(size_t)cc] = (uint32_t)tot_steps;
+                tot_rows += nrows;
+                tot_steps += ci.n_steps;
+            }
+            if (2 * max_s + max_r > avail) return 1;
+            if (ncell > 0x7FFFFFFFll / WW) return 1;
+            Schedule sch;
+            sch.geo = geo;
+            sch.B = B;
+            sch.W = W;
+            sch.nnz = n;
+            sch.cells.resize((size_t)ncell);
+            sch.subs.assign((size_t)(ncell * WW) + 2, SubDesc{0, 0});
+            std::memcpy(sch.subs.data(), dsubs.data(), sizeof(SubDesc) * (size_t)(ncell * WW));
+            for (int64_t cc = 0; cc < ncell; ++cc) {
+                const PackCellInfo& ci = info[(size_t)cc];
+                CellDesc d{};
+                d.row_off = row_off[(size_t)cc];
+                d.ent_off = ent_off[(size_t)cc];
+                d.n_steps = ci.n_steps | (ci.has_run ? kCellCritical : 0u);
+                d.nu = (uint16_t)ci.nu;
+                d.ni = (uint16_t)ci.ni;
+                sch.cells[(size_t)cc] = d;
+                const int64_t m_c = bptr[(size_t)((cc + 1) * WW)] - bptr[(size_t)(cc * WW)];
+                sch.max_cell_nnz = std::max(sch.max_cell_nnz, m_c);
+                sch.max_cell_rows = std::max<int64_t>(sch.max_cell_rows, ci.nu + ci.ni);
+                sch.max_cell_steps = std::max<int64_t>(sch.max_cell_steps, ci.crit);
+            }
+            sch.sched_cap = (int)max_s;
+            sch.lds_bytes = (int)((16 + 2 * max_s + max_r + 15) & ~(int64_t)15);
+            sch.total_rows = tot_rows;
+            sch.total_steps = tot_steps;
+            sch.n_rows_words = tot_rows + 4;
+            sch.n_entry_recs = tot_steps * G;
+            // canonical order: rounds, then blocks; a cell's ratings are contiguous
+            std::vector<int64_t> ord_off((size_t)ncell);
+            sch.cell_ptr.assign((size_t)ncell + 1, 0);
+            int64_t pos = 0;
+            for (int rd = 0; rd < B; ++rd) {
+                int64_t worst = 0;
+                for (int b = 0; b < B; ++b) {
+                    const int64_t cc = (int64_t)b * B + (b + rd) % B;
+                    sch.cell_ptr[(size_t)((int64_t)rd * B + b)] = pos;
+                    ord_off[(size_t)cc] = pos;
+                    pos += bptr[(size_t)((cc + 1) * WW)] - bptr[(size_t)(cc * WW)];
+                    worst = std::max<int64_t>(worst, info[(size_t)cc].crit);
+                }
+                sch.sum_round_steps += worst;
+            }
+            sch.cell_ptr[(size_t)ncell] = pos;
+            if (pos != n) return -1;
+            lap("  device pack: offsets");
+            prc = ext->pack_emit(prm.ingest->ctx, row_off.data(), ent_off.data(), ord_off.data(), tot_rows, tot_steps,
+                                 &sch.dev.buf);
+            if (prc != 0) return -1;
+            lap("  device pack: emit");
+            sch.device_packed = true;
+            sch.dev_ops = ext;
+            sch.device_ingest = true;
+            out = std::move(sch);
+            return 0;
+        }();
+        if (rc == 0) {
+            out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+            return 0;
+        }
+        // the host packer needs the bucket order on this side
+        sorted.resize((size_t)n);
+        if (!ext->fetch_sorted || ext->fetch_sorted(prm.ingest->ctx, sorted.data()) != 0) {
+            err = "build_schedule: could not fetch the bucket order from the device";
+            return -1;
+        }
+        lap(rc == 1 ? "  device pack: declined, host packer" : "  device pack: FAILED, host packer");
     }
     std::atomic<int> failed{0};
     std::string fail_msg;
@@ -613,7 +739,6 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         nu = (int)(std::unique(sc.us.begin(), sc.us.end()) - sc.us.begin());
         ni = (int)(std::unique(sc.is.begin(), sc.is.end()) - sc.is.begin());
     };
-    auto addressable = [&](int nrows) { return (int64_t)(nrows + 2 * G) * geo.L <= 32767; };
     auto run_parallel = [&](const std::function<void(Scratch&, std::vector<RawRat>&)>& body) {
         std::vector<std::thread> th;
         auto w = [&]() {
@@ -959,6 +1084,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     }
     lap("  release");
     out.device_ingest = on_device;
+    out.n_rows_words = (int64_t)out.rows.size();
+    out.n_entry_recs = (int64_t)out.entries.size();
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return 0;
 }

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "ingest.hpp"
+#include "records.hpp"
 
 namespace mfsgd {
 
@@ -43,44 +44,6 @@ Geometry geometry_for_k(int k);
 // two so that the next cell's can be fetched while the current cell is being applied.
 int64_t sched_bytes_for(const Geometry& geo, int W, int nrows, int64_t n_steps);
 int64_t rows_bytes_for(const Geometry& geo, int nrows);
-
-// Device-facing records (layout shared with kernels.hip).
-//
-// A cell whose LDS image would not fit is cut into CHUNKS: disjoint subsets of its users
-// (or items), each a complete little cell with its own row list, sub-cell table and steps.
-// A workgroup runs the chunks of a cell back to back (rows are stored and gathered again
-// between them); chunk order is part of the canonical order.  descs[c] for c < B*B is the
-// first chunk of cell c; further chunks live behind B*B and are linked through `next`.
-struct CellDesc {
-    uint32_t row_off;  // first entry of this chunk in rows[]
-    uint32_t ent_off;  // first step of this chunk (entries index = step * G + slot)
-    uint32_t n_steps;  // steps over all sub-cells; bit 31: the chunk carries a register-resident run
-    uint16_t nu;       // distinct users  -> LDS slots [0, nu)
-    uint16_t ni;       // distinct items  -> LDS slots [nu, nu + ni)
-    uint32_t next;     // index of the cell's next chunk, 0 = this is the last one
-    uint32_t rsv[3];
-};
-static_assert(sizeof(CellDesc) == 32, "CellDesc layout");
-constexpr uint32_t kCellCritical = 0x80000000u;
-
-struct SubDesc {
-    uint32_t off;  // first step, relative to the cell's first step (low 16 bits) | solo steps << 16
-    uint32_t n;    // general steps | run steps << 16 (run steps follow the general ones, the solo
-                   // records -- 16 bytes each, header first -- follow kSoloPad idle steps behind them)
-};
-
-constexpr int kSoloPad = 2;  // idle steps between a sub-cell's run steps and its solo records
-
-struct Entry {
-    // p-side LDS address | q-side LDS address << 16 | flag << 31; addresses in 16-byte
-    // units.  General step: flag = forward, this slot's q row is the one it updated in the
-    // previous step (take it from registers, not from LDS).  Run step: flag = idle slot.
-    uint32_t slots;
-    float r;    // the rating (RMSE pass)
-    float lrr;  // lr * r, rounded once on the host (training: s = fma(-lr, dot, lrr))
-    float ce;   // decay factor of this slot's rows: c = 1 - lr*lambda, or 1 for an idle run slot
-};
-static_assert(sizeof(Entry) == 16, "Entry layout");
 
 // Big flat arrays of the schedule: allocated without being cleared (a std::vector would
 // write 0.9 GB of zeros for 20 M ratings before the packer overwrites every byte).
@@ -125,6 +88,34 @@ private:
     size_t n_ = 0;
 };
 
+// Device buffers of a schedule the device packer built (rows, entries, order never existed on the
+// host); whoever ends up holding them frees them through `release`.
+struct DeviceSchedule {
+    DevicePacked buf{};
+    DeviceSchedule() = default;
+    DeviceSchedule(const DeviceSchedule&) = delete;
+    DeviceSchedule& operator=(const DeviceSchedule&) = delete;
+    DeviceSchedule(DeviceSchedule&& o) noexcept : buf(o.buf) { o.buf = DevicePacked{}; }
+    DeviceSchedule& operator=(DeviceSchedule&& o) noexcept {
+        if (this != &o) {
+            reset();
+            buf = o.buf;
+            o.buf = DevicePacked{};
+        }
+        return *this;
+    }
+    ~DeviceSchedule() { reset(); }
+    void reset() {
+        if (buf.release) {
+            buf.release(buf.rows);
+            buf.release(buf.entries);
+            buf.release(buf.order);
+        }
+        buf = DevicePacked{};
+    }
+    bool present() const { return buf.entries != nullptr; }
+};
+
 struct SchedParams {
     int32_t U = 0, I = 0;   // row counts of P and of this partition's Q block
     int k = 0;
@@ -141,6 +132,7 @@ struct SchedParams {
     const int64_t* degi = nullptr;
     bool validated = false;
     bool solo = true;  // allow solo runs (MFSGD_FLAG_NO_SOLO clears it: A/B measurements, tests)
+    bool device_pack = true;  // let the device pack the cells when it can (needs `ingest` with the packer)
 };
 
 struct Schedule {
@@ -161,6 +153,13 @@ struct Schedule {
     int64_t split_cells = 0;  // cells cut into more than one chunk
     double build_seconds = 0;
     bool device_ingest = false;  // degrees + bucket order came from the GPU
+    // Device-packed schedules: rows / entries / order live in `dev` only (the PodVecs above stay empty
+    // until somebody asks for a host copy); the counts are always valid.
+    bool device_packed = false;
+    DeviceSchedule dev;
+    const DeviceIngestExt* dev_ops = nullptr;  // for the host copies on demand
+    int64_t n_rows_words = 0;  // rows[] length incl. the 4 padding words
+    int64_t n_entry_recs = 0;  // entries[] length
 };
 
 // u/i are row indices into P and into this partition's Q block; orig[j] is the

@@ -314,23 +314,85 @@ def test_train_from_a_ratings_file(mf, oracle, tmp_path):
     _run(mf, oracle, d["n_users"], d["n_items"], 32, d["u"], d["i"], d["r"], epochs=2)
 
 
-def test_device_ingest_builds_the_same_schedule(mf):
-    """Degree histograms + bucket order on the GPU (ingest.hip) vs the host loops."""
+def _same_schedule(mf, U, I, k, u, i, r, n_parts=0, expect_packed=None, **kw):
+    """Builds the schedule three ways -- host loops, device ingest + host packer, device ingest + device
+    packer -- and compares every array word for word.  Returns whether the device packed it."""
     from mfsgd_amd import _lib
 
-    for name, scale in (("cfg2_ml20m", 0.02), ("cfg1_ml100k", 1.0), ("cfg4_powerlaw", 0.0003)):
+    got = []
+    for flags in (_lib.FLAG_HOST_INGEST, _lib.FLAG_DEVICE_INGEST | _lib.FLAG_HOST_PACK, _lib.FLAG_DEVICE_INGEST):
+        with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 5, flags=flags | kw.get("flags", 0), n_parts=n_parts,
+                                       **{a: b for a, b in kw.items() if a != "flags"}) as m:
+            m.set_ratings(u, i, r)
+            per_part = []
+            for part in range(max(1, n_parts)):
+                info = m.schedule_info(part)
+                per_part.append((m.order(part), m.debug_schedule(part), info))
+            got.append(per_part)
+    packed = []
+    for part in range(max(1, n_parts)):
+        ref_order, ref_sched, ref_info = got[0][part]
+        assert ref_info["device_ingest"] == 0
+        assert got[1][part][2]["device_ingest"] == 1
+        packed.append(got[2][part][2]["device_ingest"] == 2)
+        for other in (got[1][part], got[2][part]):
+            order, sched, info = other
+            np.testing.assert_array_equal(order[0], ref_order[0])
+            np.testing.assert_array_equal(order[1], ref_order[1])
+            for a, b, name in zip(sched, ref_sched, ("cells", "rows", "subs", "entries")):
+                np.testing.assert_array_equal(a, b, err_msg=name)
+            for key in ("nnz", "blocks", "waves", "lds_bytes", "total_steps", "total_rows", "max_cell_nnz", "max_cell_rows",
+                        "max_cell_steps", "sum_round_steps", "chunks", "split_cells"):
+                assert info[key] == ref_info[key], key
+    if expect_packed is not None:
+        assert all(packed) == expect_packed, packed
+    return all(packed)
+
+
+def test_device_ingest_and_device_packer_build_the_same_schedule(mf):
+    """Degree histograms + bucket order (ingest.hip) and the per-cell step packer (pack.hip) on the GPU
+    against the host loops: the same bytes, whoever builds the schedule."""
+    for name, scale, packed in (("cfg2_ml20m", 0.02, True), ("cfg1_ml100k", 1.0, True), ("cfg4_powerlaw", 0.0003, None),
+                                ("cfg3_netflix", 0.01, None), ("cfg0_dense100x80", 1.0, True)):
         w = mf.synth.workload(name, scale)
-        got = []
-        for flags in (_lib.FLAG_HOST_INGEST, _lib.FLAG_DEVICE_INGEST):
-            with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 5, flags=flags) as m:
-                m.set_ratings(w["u"], w["i"], w["r"])
-                info = m.schedule_info()
-                assert info["device_ingest"] == (1 if flags == _lib.FLAG_DEVICE_INGEST else 0)
-                got.append((m.order()[0], m.debug_schedule(), info["blocks"]))
-        assert got[0][2] == got[1][2]
-        np.testing.assert_array_equal(got[0][0], got[1][0])
-        for a, b in zip(got[0][1], got[1][1]):
-            np.testing.assert_array_equal(a, b)
+        _same_schedule(mf, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"], expect_packed=packed)
+
+
+def test_device_packer_fuzz(mf):
+    """Random small problems (sizes, skew, repeated pairs, every k and explicit B / W) through the device
+    packer: byte-identical to the host packer wherever the device takes the job."""
+    from tests.dsgd_common import fuzz_cases
+
+    n_packed = n = 0
+    for c in fuzz_cases(80, seed=4321, max_ratings=4000):
+        try:
+            n_packed += _same_schedule(mf, c["U"], c["I"], c["k"], c["u"], c["i"], c["r"], blocks=c["blocks"], waves=c["waves"])
+        except mf.MfsgdError as e:
+            assert e.code == -7, e
+            continue
+        n += 1
+    assert n >= 60 and n_packed >= n // 2, (n, n_packed)
+
+
+@pytest.mark.parametrize("k,W", [(16, 4), (64, 1), (64, 2), (128, 4), (256, 2), (32, 8)])
+def test_device_packer_runs_and_solo(mf, k, W):
+    """Hot items (runs, solo runs, idle slots, odd run lengths) and repeated pairs through the device packer."""
+    rng = np.random.default_rng(k + W)
+    U, I = 2500, 120
+    u = list(range(U)) + list(range(0, U, 2)) + list(range(0, U, 3)) + list(rng.integers(0, U, 12000)) + [5, 5, 5]
+    i = [7] * U + [11] * len(range(0, U, 2)) + [13] * len(range(0, U, 3)) + list(rng.integers(0, I, 12000)) + [7, 7, 11]
+    key = np.array(u, np.int64) * I + np.array(i)
+    key = rng.permutation(np.concatenate([np.unique(key), key[-3:]]))  # a few repeated (user, item) pairs
+    uu, ii, rr = (key // I).astype(np.int32), (key % I).astype(np.int32), (rng.random(key.size) * 4 + 1).astype(np.float32)
+    B = 16 if k == 256 else 6
+    assert _same_schedule(mf, U, I, k, uu, ii, rr, blocks=B, waves=W)
+
+
+def test_device_packer_partitioned_handles(mf):
+    """n_parts > 1: every partition's schedule through the device packer (the caller-visible rating
+    indices go through the `orig` map)."""
+    w = mf.synth.workload("cfg2_ml20m", 0.01)
+    assert _same_schedule(mf, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"], n_parts=3)
 
 
 def test_train_twice_and_new_ratings(mf, oracle):
