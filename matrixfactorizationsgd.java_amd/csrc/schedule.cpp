@@ -456,6 +456,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     }
     // ---- the device packer: every cell as a single chunk, same bytes as the host packer below -----
     if (sorted_on_device) {
+        const char* why = "";
         const int rc = [&]() -> int {
             PackRequest q;
             q.u = u;
@@ -479,17 +480,26 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             std::vector<PackCellInfo> info;
             std::vector<SubDesc> dsubs;
             int prc = ext->pack_count(prm.ingest->ctx, q, info, dsubs);
-            if (prc != 0) return prc;
+            if (prc != 0) {
+                why = "the rating set is outside the kernel's limits (cell size, ranks, LDS)";
+                return prc;
+            }
             lap("  device pack: count");
             // every cell must fit the training kernel's LDS image as ONE chunk (chunking is the host's job)
             int64_t max_s = min_sched, max_r = min_rows, tot_rows = 0, tot_steps = 0;
             std::vector<uint32_t> row_off((size_t)ncell), ent_off((size_t)ncell);
             for (int64_t cc = 0; cc < ncell; ++cc) {
                 const PackCellInfo& ci = info[(size_t)cc];
-                if (ci.status != 0) return 1;
+                if (ci.status != 0) {
+                    why = "a cell overflowed the kernel's arrays or counters";
+                    return 1;
+                }
                 const int nrows = (int)(ci.nu + ci.ni);
                 if (ci.n_steps != 0) {
-                    if (!addressable(nrows) || rows_bytes_for(geo, nrows) + 2 * min_sched > avail) return 1;
+                    if (!addressable(nrows) || rows_bytes_for(geo, nrows) + 2 * min_sched > avail) {
+                        why = "a cell's rows exceed the training kernel's LDS image";
+                        return 1;
+                    }
                     max_s = std::max(max_s, sched_bytes_for(geo, W, nrows, (int64_t)ci.n_steps));
                     max_r = std::max(max_r, rows_bytes_for(geo, nrows));
                 }
@@ -499,7 +509,10 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 tot_rows += nrows;
                 tot_steps += ci.n_steps;
             }
-            if (2 * max_s + max_r > avail) return 1;
+            if (2 * max_s + max_r > avail) {
+                why = "cells have to be chunked";
+                return 1;
+            }
             if (ncell > 0x7FFFFFFFll / WW) return 1;
             Schedule sch;
             sch.geo = geo;
@@ -567,7 +580,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             err = "build_schedule: could not fetch the bucket order from the device";
             return -1;
         }
-        lap(rc == 1 ? "  device pack: declined, host packer" : "  device pack: FAILED, host packer");
+        if (trace) std::fprintf(stderr, "[schedule]   device pack %s: %s\n", rc == 1 ? "declined" : "FAILED", why);
+        lap("  bucket order to the host");
     }
     std::atomic<int> failed{0};
     std::string fail_msg;
