@@ -196,10 +196,10 @@ void default_item_map(mfsgd_handle* h) {
     h->custom_item_map = false;
 }
 
-// d_sync: done[B] words (kDoneStride apart), then 4 words zeroed with them before every launch (the
-// first counts the workgroups that have arrived), then {abort code, launches that started, -, -}.
+// d_sync: done[B] words (kDoneStride apart), then {arrivals, generation, -, -} of the kernel's start-of-launch
+// barrier, then {abort code, launches that started, -, -}.  Zeroed once, when allocated; the kernel keeps it
+// consistent from launch to launch by itself.
 size_t sync_bytes(const Part& p) { return ((size_t)p.sched.B * kDoneStride + 8) * sizeof(unsigned); }
-size_t sync_zeroed_bytes(const Part& p) { return ((size_t)p.sched.B * kDoneStride + 4) * sizeof(unsigned); }
 unsigned* abort_word(const Part& p) { return static_cast<unsigned*>(p.d_sync.p) + (size_t)p.sched.B * kDoneStride + 4; }
 
 int ensure_part_on_device(mfsgd_handle* h, Part& p) {
@@ -225,6 +225,7 @@ int ensure_part_on_device(mfsgd_handle* h, Part& p) {
     if ((rc = dev_alloc(h, p.d_sse_out, sizeof(double)))) return rc;
     if ((rc = dev_alloc(h, p.d_sync, sync_bytes(p)))) return rc;
     HIPCHK(h, hipMemset(p.d_sync.p, 0, sync_bytes(p)));
+    HIPCHK(h, hipDeviceSynchronize());  // (memset is asynchronous; the first launch may be on another stream)
     p.on_device = true;
     return MFSGD_OK;
 }
@@ -297,7 +298,8 @@ int launch_epoch_body(mfsgd_handle* h, Part& p, float* Q, hipStream_t st) {
         CellLaunch a = make_launch(h, p, Q);
         a.grid = p.persistent_np;
         // flags are counted within the launch: zero them (and the abort word) every time
-        HIPCHK(h, hipMemsetAsync(p.d_sync.p, 0, sync_zeroed_bytes(p), st));
+        // no memset: the kernel resets its own hand-off flags behind a device-side barrier (kernels.hip,
+        // run_ring) -- a memset node in a replayed graph is not reliably ordered before the kernel node
         HIPCHK(h, launch_epoch_persistent(h->geo.L, p.sched.W, a, p.sched.B, static_cast<unsigned*>(p.d_sync.p),
                                           abort_word(p), st));
         return MFSGD_OK;
@@ -350,7 +352,14 @@ int check_abort(mfsgd_handle* h, Part& p, unsigned* started = nullptr) {
     unsigned w[2] = {0, 0};
     HIPCHK(h, hipMemcpy(w, abort_word(p), sizeof w, hipMemcpyDeviceToHost));
     if (started) *started = w[1];
-    if (w[0] != 0 || w[1] != 0) (void)hipMemset(abort_word(p), 0, sizeof w);
+    if (w[0] != 0 || w[1] != 0) {
+        // the device is idle on this stream (the caller has synchronised); a give-up also leaves arrivals behind
+        const unsigned zeros[6] = {0, 0, 0, 0, 0, 0};
+        if (w[0] != 0)
+            (void)hipMemcpy(abort_word(p) - 4, zeros, sizeof zeros, hipMemcpyHostToDevice);
+        else
+            (void)hipMemcpy(abort_word(p), zeros, 2 * sizeof(unsigned), hipMemcpyHostToDevice);
+    }
     if (w[0] == 2u) return kNotResident;
     if (w[0] != 0)
         return fail(h, MFSGD_ERR_HIP, "persistent epoch kernel timed out waiting for a tile hand-off (results invalid)");
@@ -1097,7 +1106,6 @@ int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgro
     a.diag = true;
     a.sse_partial = static_cast<double*>(p.d_sse_partial.p);
     HIPCHK(h, hipMemsetAsync(p.d_sse_partial.p, 0, words * sizeof(uint64_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(p.d_sync.p, 0, sync_zeroed_bytes(p), h->stream));
     HIPCHK(h, launch_epoch_persistent(h->geo.L, p.sched.W, a, p.sched.B, static_cast<unsigned*>(p.d_sync.p), abort_word(p), h->stream));
     HIPCHK(h, hipMemcpyAsync(out, p.d_sse_partial.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -654,31 +654,48 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     Cell<L, W, NH> cx;
     cx.init_thread();
     cx.fail_flag = ctl;
-    // Residency check before anything is touched: every workgroup of the launch announces itself and
-    // waits until all NP have (abort_word[-4] counts arrivals; the host zeroes it with the flags).  The
-    // hand-off protocol below needs all of them on the chip at once; when they are not -- another
-    // kernel holds CUs -- the launch gives up HERE, with the factors untouched (abort code 2), and the
-    // host runs the epoch as one launch per round instead.  A launch that finds the abort word already
-    // set (an earlier launch of the same stream gave up) does nothing either.
+    // Start-of-launch rendezvous, before anything is touched.  It does two jobs with one device-side
+    // barrier (sense reversing: abort_word[-4] counts arrivals, abort_word[-3] is the generation):
+    //  * the hand-off flags are reset HERE, by their owners (block b's flag by the workgroup that runs
+    //    block b), and nobody proceeds until everybody has -- the host zeroes nothing between launches
+    //    (a memset node in a replayed hipGraph was measured NOT to be reliably ordered before the kernel
+    //    node behind it: flags still standing from the previous epoch let consumers run ahead of their
+    //    producers);
+    //  * it proves that all NP workgroups are on the chip at once, which the hand-off protocol needs.
+    //    When they are not -- another kernel holds CUs -- the launch gives up with the factors untouched
+    //    (abort code 2) and the host runs the epoch as one launch per round instead.  A launch that finds
+    //    the abort word already set (an earlier launch of the same stream gave up) does nothing either.
     if (cx.tid == 0) {
         unsigned bad = __hip_atomic_load((gu32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (bad == 0u) {
             gu32* arrive = (gu32*)(abort_word - 4);
-            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)NP) {
-                __builtin_amdgcn_s_sleep(8);
-                if ((++spins & 63u) == 0u) {
-                    bad = __hip_atomic_load((gu32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (bad == 0u && spins > (1u << 19)) {
-                        unsigned expected = 0u;  // only the first one to give up sets the code
-                        __hip_atomic_compare_exchange_strong((gu32*)abort_word, &expected, 2u, __ATOMIC_RELAXED,
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        bad = 2u;
+            gu32* gen = (gu32*)(abort_word - 3);
+            for (int b = wg; b < B; b += NP)
+                __hip_atomic_store((gu32*)(done + (size_t)b * kFlagStride), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // before arriving
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // my flags are zero before my arrival counts
+            const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned)NP - 1u) {
+                __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(gen, g0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                unsigned spins = 0;
+                while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if ((++spins & 63u) == 0u) {
+                        bad = __hip_atomic_load((gu32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (bad == 0u && spins > (1u << 19)) {
+                            unsigned expected = 0u;  // only the first one to give up sets the code
+                            __hip_atomic_compare_exchange_strong((gu32*)abort_word, &expected, 2u, __ATOMIC_RELAXED,
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            bad = 2u;
+                        }
+                        if (bad != 0u) break;
                     }
-                    if (bad != 0u) break;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         ctl[0] = bad != 0u ? 1u : 0u;
         ctl[1] = bad;
