@@ -77,16 +77,20 @@ def cpu_baseline(w, m, budget_s=12.0):
 
 
 def read_traffic(workload, k, nnz):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary, if one matches."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("workload") == workload and t.get("k") == k and t.get("nnz") == nnz:
-            return t.get("hbm_bytes_per_launch")
-    except Exception:
-        pass
-    return None
+    """HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, rocprofv3 PMC passes of THIS round's build, tools/prof.sh)
+    from the committed summary of the same workload, if there is one.  It is a profile of the same command
+    taken under rocprofv3, not a counter read inside this run (PMC collection needs the profiler)."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("workload") == workload and t.get("k") == k and t.get("nnz") == nnz:
+                return t.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
+        except Exception:
+            pass
+    return None, None
 
 
 def main():
@@ -291,6 +295,7 @@ def main():
     avg_launch_s = (dev_ms / 1e3) / max(1, launches)  # N > 1: partitions of a group run concurrently
     units_per_launch = nnz * args.steps / max(1, launches)  # per rank
     achieved_gbs = units_per_launch * bytes_per_update / avg_launch_s / 1e9  # per GPU
+    traffic, traffic_source = read_traffic(args.workload, k, nnz) if world == 1 else (None, None)
     roofline = {
         # "hbm" is the roofline this path is priced against (gather + axpy, 0.74 flop/B).  `achieved` is
         # ALGORITHMIC bytes / time, a throughput yardstick: what actually limits a skewed epoch is the longest
@@ -304,7 +309,8 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved_gbs / HBM_PEAK_GBS,
-        "traffic": read_traffic(args.workload, k, nnz) if world == 1 else None,
+        "traffic": traffic,
+        "traffic_source": traffic_source,
         "bytes_per_update": bytes_per_update,
         "updates_per_launch": units_per_launch,
         "avg_launch_us": avg_launch_s * 1e6,

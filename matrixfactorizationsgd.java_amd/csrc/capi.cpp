@@ -962,8 +962,10 @@ int mfsgd_recommend(mfsgd_handle* h, const int32_t* users, int32_t n_users, int3
     int rc = factors_to_device(h);
     if (rc) return rc;
     const int32_t I = h->cfg.n_items;
-    // users per batch: about 64 M scores at a time
+    const bool fused = recommend_is_fused(I, topn);  // score + select in one kernel, no score buffers
+    // users per batch: about 64 M scores at a time (the sort path materialises them)
     int batch = (int)std::max<int64_t>(1, std::min<int64_t>(n_users, ((int64_t)64 << 20) / std::max(1, I)));
+    if (fused) batch = n_users;
     batch = std::min(batch, 65535);
     DevBuf d_users, s_in, s_out, id_in, id_out, d_off, o_s, o_i;
     void* temp = nullptr;
@@ -975,11 +977,13 @@ int mfsgd_recommend(mfsgd_handle* h, const int32_t* users, int32_t n_users, int3
     };
     const size_t cells = (size_t)batch * (size_t)I;
     rc = dev_alloc(h, d_users, sizeof(int32_t) * (size_t)batch);
-    if (!rc) rc = dev_alloc(h, s_in, 4 * cells);
-    if (!rc) rc = dev_alloc(h, s_out, 4 * cells);
-    if (!rc) rc = dev_alloc(h, id_in, 4 * cells);
-    if (!rc) rc = dev_alloc(h, id_out, 4 * cells);
-    if (!rc) rc = dev_alloc(h, d_off, sizeof(long long) * ((size_t)batch + 1));
+    if (!fused) {
+        if (!rc) rc = dev_alloc(h, s_in, 4 * cells);
+        if (!rc) rc = dev_alloc(h, s_out, 4 * cells);
+        if (!rc) rc = dev_alloc(h, id_in, 4 * cells);
+        if (!rc) rc = dev_alloc(h, id_out, 4 * cells);
+        if (!rc) rc = dev_alloc(h, d_off, sizeof(long long) * ((size_t)batch + 1));
+    }
     if (!rc) rc = dev_alloc(h, o_s, 4 * (size_t)batch * topn);
     if (!rc) rc = dev_alloc(h, o_i, 4 * (size_t)batch * topn);
     if (rc) {
@@ -990,7 +994,11 @@ int mfsgd_recommend(mfsgd_handle* h, const int32_t* users, int32_t n_users, int3
     for (int32_t done = 0; done < n_users && e == hipSuccess; done += batch) {
         const int nb = std::min<int32_t>(batch, n_users - done);
         e = hipMemcpyAsync(d_users.p, users + done, sizeof(int32_t) * (size_t)nb, hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess)
+        if (e == hipSuccess && fused)
+            e = recommend_fused(h->geo.L, static_cast<const float*>(h->dP.p), static_cast<const float*>(h->dQ.p),
+                                static_cast<const int32_t*>(d_users.p), nb, I, topn, static_cast<float*>(o_s.p),
+                                static_cast<int32_t*>(o_i.p), h->stream);
+        else if (e == hipSuccess)
             e = recommend_batch(h->geo.L, static_cast<const float*>(h->dP.p), static_cast<const float*>(h->dQ.p),
                                 static_cast<const int32_t*>(d_users.p), nb, I, topn, static_cast<float*>(s_in.p),
                                 static_cast<float*>(s_out.p), static_cast<int32_t*>(id_in.p), static_cast<int32_t*>(id_out.p),

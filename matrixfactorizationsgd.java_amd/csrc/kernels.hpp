@@ -45,7 +45,12 @@ hipError_t launch_predict(int L, const float* P, const float* Q, const int32_t* 
 // Diagnostic (tests): `workgroups` one-wave workgroups, each holding lds_bytes of LDS, spin for `ticks` x 10 ns.
 hipError_t launch_occupy(int workgroups, int lds_bytes, unsigned long long ticks, hipStream_t st);
 
-// recommend.hip: scores of nb users against every item, top `topn` of each into out_s / out_i.
+// recommend.hip: fused score + select (one workgroup per user, nothing but the winners goes to memory) for
+// the (n_items, topn) recommend_is_fused() accepts ...
+bool recommend_is_fused(int32_t n_items, int32_t topn);
+hipError_t recommend_fused(int L, const float* P, const float* Q, const int32_t* d_users, int nb, int32_t n_items,
+                           int32_t topn, float* out_s, int32_t* out_i, hipStream_t st);
+// ... and for the rest: scores of nb users against every item, top `topn` of each into out_s / out_i.
 hipError_t recommend_batch(int L, const float* P, const float* Q, const int32_t* d_users, int nb, int32_t n_items,
                            int32_t topn, float* s_in, float* s_out, int32_t* id_in, int32_t* id_out, long long* d_off,
                            void*& temp, size_t& temp_bytes, float* out_s, int32_t* out_i, hipStream_t st);

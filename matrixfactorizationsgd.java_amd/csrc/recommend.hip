@@ -2,12 +2,17 @@
 // the largest dot(P[u], Q[i]), ties broken by the smaller item index.  Scores use the canonical
 // dot of DESIGN.md section 3, so they are bit-identical to mfsgd_predict() and to the oracle.
 // Score pass: one lane group per (user, item) pair, the user's row held in registers across
-// items.  Selection: one stable, descending segmented radix sort per batch of users (rocPRIM).
+// items.  Selection, for topn <= kTopnFused: fused behind the scores in ONE kernel -- a workgroup per
+// user keeps the scores of a tile of items in LDS as order-preserving integers, finds the topn-th
+// largest by a 4 x 8-bit radix select on LDS histograms, collects what lies above it (ties in
+// ascending item order) and sorts only those; no score ever goes to memory.  Larger topn: scores to
+// memory and one stable, descending segmented radix sort per batch of users (rocPRIM).
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include <cstdint>
 
+#include "canon.hpp"
 #include "kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -15,39 +20,6 @@
 namespace mfsgd {
 
 namespace {
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v) {
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float swap_add16(float v) {
-    float t;
-    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v), "=&v"(t));
-    return v + t;
-}
-__device__ __forceinline__ float swap_add32(float v) {
-    float t;
-    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v), "=&v"(t));
-    return v + t;
-}
-template <int L>
-__device__ __forceinline__ float group_allreduce(float v) {
-    if constexpr (L >= 2) v = v + dpp_move<0xB1>(v);
-    if constexpr (L >= 4) v = v + dpp_move<0x4E>(v);
-    if constexpr (L >= 8) v = v + dpp_move<0x141>(v);
-    if constexpr (L >= 16) v = v + dpp_move<0x140>(v);
-    if constexpr (L >= 32) v = swap_add16(v);
-    if constexpr (L >= 64) v = swap_add32(v);
-    return v;
-}
-__device__ __forceinline__ float chunk_dot(const float4 p, const float4 q) {
-    float t0 = p.x * q.x;
-    float t1 = p.y * q.y;
-    t0 = __builtin_fmaf(p.z, q.z, t0);
-    t1 = __builtin_fmaf(p.w, q.w, t1);
-    return t0 + t1;
-}
 
 // scores[b * n_items + i] = dot(P[users[b]], Q[i]); ids[...] = i.  grid = (item blocks, users)
 template <int L>
@@ -72,6 +44,175 @@ __global__ void __launch_bounds__(256) score_kernel(const float* __restrict__ P,
             ids[(size_t)b * n_items + i] = i;
         }
     }
+}
+
+// ---- fused score + select ----------------------------------------------------------------------------
+constexpr int kTopnFused = 128;    // largest topn the fused kernel takes
+constexpr int kTopnTile = 28672;   // items scored per tile (112 KiB of keys in LDS)
+constexpr int kTopnCand = 2048;    // candidates kept across tiles (tiles x topn must fit)
+
+// float -> unsigned whose order is the float order (-0 counts as +0, as a comparison would)
+__device__ __forceinline__ unsigned order_key(float f) {
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int L>
+__global__ void __launch_bounds__(256) topn_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                   const int32_t* __restrict__ users, const int32_t n_items,
+                                                   const int32_t topn, float* __restrict__ out_s,
+                                                   int32_t* __restrict__ out_i) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* keys = reinterpret_cast<unsigned*>(smem);                                   // kTopnTile
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(keys + kTopnTile);   // kTopnCand
+    unsigned* hist = reinterpret_cast<unsigned*>(cand + kTopnCand);                        // 256
+    int* ctl = reinterpret_cast<int*>(hist + 256);  // [0] candidates so far, [1] bin, [2] need, [3] ties taken
+    constexpr int KP = 4 * L;
+    constexpr int GPB = 256 / L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lig = tid % L, grp = tid / L;
+    const int b = blockIdx.x;
+    const float4 p = *reinterpret_cast<const float4*>(P + (size_t)users[b] * KP + lig * 4);
+    if (tid == 0) ctl[0] = 0;
+    __syncthreads();
+    for (int tile0 = 0; tile0 < n_items; tile0 += kTopnTile) {
+        const int nt = min(kTopnTile, n_items - tile0);
+        // scores of the tile (uniform trip count: the DPP reduction needs every lane live)
+        const int iters = (nt + GPB - 1) / GPB;
+        for (int it = 0; it < iters; ++it) {
+            const int x = grp + it * GPB;
+            const bool ok = x < nt;
+            const float4 q = *reinterpret_cast<const float4*>(Q + (size_t)(ok ? tile0 + x : 0) * KP + lig * 4);
+            const float d = group_allreduce<L>(chunk_dot(p, q));
+            if (ok && lig == 0) keys[x] = order_key(d);
+        }
+        __syncthreads();
+        // radix select: the key of the need-th largest score of the tile
+        int need = min(topn, nt);
+        const int take = need;
+        unsigned prefix = 0u, mask = 0u;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[tid] = 0u;
+            __syncthreads();
+            for (int x = tid; x < nt; x += 256) {
+                const unsigned kx = keys[x];
+                if ((kx & mask) == prefix) atomicAdd(&hist[(kx >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                // bins from the top: lane l owns bins 255 - 4l .. 252 - 4l; suffix counts by a wave scan
+                unsigned h[4], own = 0;
+                for (int j = 0; j < 4; ++j) {
+                    h[j] = hist[255 - 4 * lane - j];
+                    own += h[j];
+                }
+                unsigned incl = own;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned o = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += o;
+                }
+                unsigned above = incl - own;  // scores in bins above this lane's
+                if (above < (unsigned)need && incl >= (unsigned)need) {
+                    for (int j = 0; j < 4; ++j) {
+                        if (above + h[j] >= (unsigned)need) {
+                            ctl[1] = 255 - 4 * lane - j;
+                            ctl[2] = need - (int)above;
+                            break;
+                        }
+                        above += h[j];
+                    }
+                }
+            }
+            __syncthreads();
+            prefix |= (unsigned)ctl[1] << shift;
+            mask |= 0xFFu << shift;
+            need = ctl[2];
+            __syncthreads();
+        }
+        // everything above the threshold, then `need` of the ties in ascending item order
+        const unsigned T = prefix;
+        const int base = ctl[0];
+        if (tid == 0) ctl[3] = 0;
+        __syncthreads();
+        // ties: each thread owns a contiguous slice, so that "first `need` by index" is a prefix over threads
+        const int per = (nt + 255) / 256, lo = tid * per, hi = min(nt, lo + per);
+        int ties = 0;
+        for (int x = lo; x < hi; ++x) ties += keys[x] == T ? 1 : 0;
+        // exclusive prefix of `ties` over the 256 threads (hist[] is free now)
+        hist[tid] = (unsigned)ties;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned run = 0;
+            for (int x = 0; x < 256; ++x) {
+                const unsigned v = hist[x];
+                hist[x] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+        int tie_rank = (int)hist[tid];
+        for (int x = lo; x < hi; ++x) {
+            const unsigned kx = keys[x];
+            bool sel = kx > T;
+            if (kx == T) {
+                sel = tie_rank < need;
+                ++tie_rank;
+            }
+            if (sel) {
+                const int at = atomicAdd(&ctl[0], 1);
+                // ascending sort of this = score descending, then item ascending
+                if (at < kTopnCand) cand[at] = ((unsigned long long)(~kx) << 32) | (unsigned)(tile0 + x);
+            }
+        }
+        __syncthreads();
+        (void)base;
+        (void)take;
+    }
+    // ---- the candidates of all tiles: bitonic sort, best first -----------------------------------------
+    const int nc = min(ctl[0], kTopnCand);
+    int n2 = 1;
+    while (n2 < nc) n2 <<= 1;
+    for (int x = nc + tid; x < n2; x += 256) cand[x] = ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int x = tid; x < n2 / 2; x += 256) {
+                const int i0 = 2 * x - (x & (stride - 1)), i1 = i0 + stride;
+                const bool up = (i0 & size) == 0;
+                const unsigned long long a0 = cand[i0], a1 = cand[i1];
+                if ((a0 > a1) == up) {
+                    cand[i0] = a1;
+                    cand[i1] = a0;
+                }
+            }
+            __syncthreads();
+        }
+    // the winners; their scores recomputed with the canonical dot (the bits predict() returns)
+    const int iters = (topn + GPB - 1) / GPB;
+    for (int it = 0; it < iters; ++it) {
+        const int x = grp + it * GPB;
+        const bool ok = x < topn;
+        const int item = ok ? (int)(cand[x] & 0xFFFFFFFFull) : 0;
+        const float4 q = *reinterpret_cast<const float4*>(Q + (size_t)item * KP + lig * 4);
+        const float d = group_allreduce<L>(chunk_dot(p, q));
+        if (ok && lig == 0) {
+            out_s[(size_t)b * topn + x] = d;
+            out_i[(size_t)b * topn + x] = item;
+        }
+    }
+}
+
+template <int L>
+hipError_t topn_L(const float* P, const float* Q, const int32_t* users, int nb, int32_t n_items, int32_t topn, float* out_s,
+                  int32_t* out_i, hipStream_t st) {
+    const size_t lds = (size_t)kTopnTile * 4 + (size_t)kTopnCand * 8 + 256 * 4 + 16;
+    hipError_t e = hipFuncSetAttribute((const void*)topn_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((topn_kernel<L>), dim3((unsigned)nb), dim3(256), lds, st, P, Q, users, n_items, topn, out_s, out_i);
+    return hipGetLastError();
 }
 
 __global__ void __launch_bounds__(256) take_top_kernel(const float* __restrict__ s, const int32_t* __restrict__ id,
@@ -99,6 +240,26 @@ hipError_t score_L(const float* P, const float* Q, const int32_t* users, int nb,
 }
 
 }  // namespace
+
+bool recommend_is_fused(int32_t n_items, int32_t topn) {
+    const long long tiles = ((long long)n_items + kTopnTile - 1) / kTopnTile;
+    return topn <= kTopnFused && tiles * topn <= kTopnCand;
+}
+
+// Fused score + select: no score buffers at all.
+hipError_t recommend_fused(int L, const float* P, const float* Q, const int32_t* d_users, int nb, int32_t n_items,
+                           int32_t topn, float* out_s, int32_t* out_i, hipStream_t st) {
+    switch (L) {
+        case 1: return topn_L<1>(P, Q, d_users, nb, n_items, topn, out_s, out_i, st);
+        case 2: return topn_L<2>(P, Q, d_users, nb, n_items, topn, out_s, out_i, st);
+        case 4: return topn_L<4>(P, Q, d_users, nb, n_items, topn, out_s, out_i, st);
+        case 8: return topn_L<8>(P, Q, d_users, nb, n_items, topn, out_s, out_i, st);
+        case 16: return topn_L<16>(P, Q, d_users, nb, n_items, topn, out_s, out_i, st);
+        case 32: return topn_L<32>(P, Q, d_users, nb, n_items, topn, out_s, out_i, st);
+        case 64: return topn_L<64>(P, Q, d_users, nb, n_items, topn, out_s, out_i, st);
+        default: return hipErrorInvalidValue;
+    }
+}
 
 // Device buffers are the caller's (capi.cpp): scores/ids in and out (nb * n_items each), offsets nb+1.
 hipError_t recommend_batch(int L, const float* P, const float* Q, const int32_t* d_users, int nb, int32_t n_items,

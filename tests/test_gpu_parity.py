@@ -300,6 +300,33 @@ def test_recommend_topn_equals_sorted_predictions(mf, oracle, k):
         np.testing.assert_array_equal(scores[row], s[order])
 
 
+@pytest.mark.parametrize("I,topn,k", [(30000, 10, 64), (61000, 40, 32), (700, 128, 8), (700, 129, 8), (5, 5, 16)])
+def test_recommend_fused_select_and_sort_paths(mf, oracle, I, topn, k):
+    """The fused score + radix-select kernel (topn <= 128: one tile, three tiles) and the segmented-sort
+    path (topn = 129) against sorting the oracle's predictions; many exact ties, including ties that
+    straddle the selection threshold, and -0.0 / +0.0."""
+    rng = np.random.default_rng(I + topn)
+    U = 40
+    P = rng.standard_normal((U, k)).astype(np.float32)
+    Q = rng.standard_normal((I, k)).astype(np.float32)
+    Q[rng.integers(0, I, I // 3)] = Q[3 % I]  # a third of the catalogue scores exactly alike
+    if I > 100:
+        Q[50:60] = 0.0  # zero scores ...
+        Q[55, 0] = -0.0  # (a -0.0 that must tie with them)
+        P[7] = np.abs(P[7])
+        Q[60:5000:7] = -np.abs(Q[60:5000:7])  # ... in the middle of user 7's ranking
+    users = np.array([0, 7, 7, U - 1, 13, 21], np.int32)
+    with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 1) as m:
+        m.set_factors(P, Q)
+        items, scores = m.recommend(users, topn)
+    allitems = np.arange(I, dtype=np.int32)
+    for row, u in enumerate(users):
+        sc = oracle.predict(P, Q, np.full(I, u, np.int32), allitems)
+        order = np.lexsort((allitems, -sc.astype(np.float64)))[:topn]
+        np.testing.assert_array_equal(items[row], order)
+        np.testing.assert_array_equal(scores[row], sc[order])
+
+
 def test_train_from_a_ratings_file(mf, oracle, tmp_path):
     rng = np.random.default_rng(12)
     U, I, n = 400, 300, 9000
