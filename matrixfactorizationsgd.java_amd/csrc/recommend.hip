@@ -58,18 +58,22 @@ __device__ __forceinline__ unsigned order_key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+constexpr int kTopnThreads = 1024;  // 16 waves: the scores are a latency-bound row gather, so many loads in flight
+
 template <int L>
-__global__ void __launch_bounds__(256) topn_kernel(const float* __restrict__ P, const float* __restrict__ Q,
-                                                   const int32_t* __restrict__ users, const int32_t n_items,
-                                                   const int32_t topn, float* __restrict__ out_s,
-                                                   int32_t* __restrict__ out_i) {
+__global__ void __launch_bounds__(kTopnThreads) topn_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                            const int32_t* __restrict__ users, const int32_t n_items,
+                                                            const int32_t topn, float* __restrict__ out_s,
+                                                            int32_t* __restrict__ out_i) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = kTopnThreads, NW = NT / 64;
     unsigned* keys = reinterpret_cast<unsigned*>(smem);                                   // kTopnTile
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(keys + kTopnTile);   // kTopnCand
     unsigned* hist = reinterpret_cast<unsigned*>(cand + kTopnCand);                        // 256
-    int* ctl = reinterpret_cast<int*>(hist + 256);  // [0] candidates so far, [1] bin, [2] need, [3] ties taken
+    unsigned* wtot = hist + 256;                                                           // NW wave totals
+    int* ctl = reinterpret_cast<int*>(wtot + NW);  // [0] candidates so far, [1] bin, [2] need
     constexpr int KP = 4 * L;
-    constexpr int GPB = 256 / L;
+    constexpr int GPB = NT / L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lig = tid % L, grp = tid / L;
     const int b = blockIdx.x;
@@ -78,9 +82,22 @@ __global__ void __launch_bounds__(256) topn_kernel(const float* __restrict__ P, 
     __syncthreads();
     for (int tile0 = 0; tile0 < n_items; tile0 += kTopnTile) {
         const int nt = min(kTopnTile, n_items - tile0);
-        // scores of the tile (uniform trip count: the DPP reduction needs every lane live)
+        // scores of the tile (uniform trip count: the DPP reduction needs every lane live), two rows in flight
         const int iters = (nt + GPB - 1) / GPB;
-        for (int it = 0; it < iters; ++it) {
+        int it = 0;
+        for (; it + 1 < iters; it += 2) {
+            const int x0 = grp + it * GPB, x1 = x0 + GPB;
+            const bool ok1 = x1 < nt;
+            const float4 q0 = *reinterpret_cast<const float4*>(Q + (size_t)(tile0 + x0) * KP + lig * 4);
+            const float4 q1 = *reinterpret_cast<const float4*>(Q + (size_t)(ok1 ? tile0 + x1 : 0) * KP + lig * 4);
+            const float d0 = group_allreduce<L>(chunk_dot(p, q0));
+            const float d1 = group_allreduce<L>(chunk_dot(p, q1));
+            if (lig == 0) {
+                keys[x0] = order_key(d0);
+                if (ok1) keys[x1] = order_key(d1);
+            }
+        }
+        for (; it < iters; ++it) {
             const int x = grp + it * GPB;
             const bool ok = x < nt;
             const float4 q = *reinterpret_cast<const float4*>(Q + (size_t)(ok ? tile0 + x : 0) * KP + lig * 4);
@@ -90,19 +107,30 @@ __global__ void __launch_bounds__(256) topn_kernel(const float* __restrict__ P, 
         __syncthreads();
         // radix select: the key of the need-th largest score of the tile
         int need = min(topn, nt);
-        const int take = need;
         unsigned prefix = 0u, mask = 0u;
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 24 - 8 * pass;
-            hist[tid] = 0u;
+            if (tid < 256) hist[tid] = 0u;
             __syncthreads();
-            for (int x = tid; x < nt; x += 256) {
-                const unsigned kx = keys[x];
-                if ((kx & mask) == prefix) atomicAdd(&hist[(kx >> shift) & 255u], 1u);
+            // scores cluster in a few bins (the first digit is sign + exponent): one atomic per distinct bin
+            // of a wave, not one per lane
+            for (int x0 = wave * 64; x0 < nt; x0 += NT) {
+                const int x = x0 + lane;
+                const unsigned kx = x < nt ? keys[x] : 0u;
+                const bool act = x < nt && (kx & mask) == prefix;
+                const unsigned bin = (kx >> shift) & 255u;
+                unsigned long long todo = __ballot(act);
+                while (todo) {
+                    const int leader = __builtin_ctzll(todo);
+                    const unsigned lb = __shfl(bin, leader, 64);
+                    const unsigned long long same = __ballot(act && bin == lb);
+                    if (lane == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+                    todo &= ~same;
+                }
             }
             __syncthreads();
             if (wave == 0) {
-                // bins from the top: lane l owns bins 255 - 4l .. 252 - 4l; suffix counts by a wave scan
+                // bins from the top: lane l owns bins 255 - 4l .. 252 - 4l; counts above by a wave scan
                 unsigned h[4], own = 0;
                 for (int j = 0; j < 4; ++j) {
                     h[j] = hist[255 - 4 * lane - j];
@@ -132,28 +160,22 @@ __global__ void __launch_bounds__(256) topn_kernel(const float* __restrict__ P, 
             need = ctl[2];
             __syncthreads();
         }
-        // everything above the threshold, then `need` of the ties in ascending item order
+        // everything above the threshold, then `need` of the ties in ascending item order: each thread owns a
+        // contiguous slice, so that "the first `need` by index" is a prefix over threads
         const unsigned T = prefix;
-        const int base = ctl[0];
-        if (tid == 0) ctl[3] = 0;
-        __syncthreads();
-        // ties: each thread owns a contiguous slice, so that "first `need` by index" is a prefix over threads
-        const int per = (nt + 255) / 256, lo = tid * per, hi = min(nt, lo + per);
+        const int per = (nt + NT - 1) / NT, lo = min(nt, tid * per), hi = min(nt, lo + per);
         int ties = 0;
         for (int x = lo; x < hi; ++x) ties += keys[x] == T ? 1 : 0;
-        // exclusive prefix of `ties` over the 256 threads (hist[] is free now)
-        hist[tid] = (unsigned)ties;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned run = 0;
-            for (int x = 0; x < 256; ++x) {
-                const unsigned v = hist[x];
-                hist[x] = run;
-                run += v;
-            }
+        int incl = ties;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
         }
+        if (lane == 63) wtot[wave] = (unsigned)incl;
         __syncthreads();
-        int tie_rank = (int)hist[tid];
+        int tie_rank = incl - ties;
+        for (int w2 = 0; w2 < wave; ++w2) tie_rank += (int)wtot[w2];
         for (int x = lo; x < hi; ++x) {
             const unsigned kx = keys[x];
             bool sel = kx > T;
@@ -168,18 +190,16 @@ __global__ void __launch_bounds__(256) topn_kernel(const float* __restrict__ P, 
             }
         }
         __syncthreads();
-        (void)base;
-        (void)take;
     }
     // ---- the candidates of all tiles: bitonic sort, best first -----------------------------------------
     const int nc = min(ctl[0], kTopnCand);
     int n2 = 1;
     while (n2 < nc) n2 <<= 1;
-    for (int x = nc + tid; x < n2; x += 256) cand[x] = ~0ull;
+    for (int x = nc + tid; x < n2; x += NT) cand[x] = ~0ull;
     __syncthreads();
     for (int size = 2; size <= n2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int x = tid; x < n2 / 2; x += 256) {
+            for (int x = tid; x < n2 / 2; x += NT) {
                 const int i0 = 2 * x - (x & (stride - 1)), i1 = i0 + stride;
                 const bool up = (i0 & size) == 0;
                 const unsigned long long a0 = cand[i0], a1 = cand[i1];
@@ -208,10 +228,10 @@ __global__ void __launch_bounds__(256) topn_kernel(const float* __restrict__ P, 
 template <int L>
 hipError_t topn_L(const float* P, const float* Q, const int32_t* users, int nb, int32_t n_items, int32_t topn, float* out_s,
                   int32_t* out_i, hipStream_t st) {
-    const size_t lds = (size_t)kTopnTile * 4 + (size_t)kTopnCand * 8 + 256 * 4 + 16;
+    const size_t lds = (size_t)kTopnTile * 4 + (size_t)kTopnCand * 8 + 256 * 4 + (kTopnThreads / 64) * 4 + 16;
     hipError_t e = hipFuncSetAttribute((const void*)topn_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((topn_kernel<L>), dim3((unsigned)nb), dim3(256), lds, st, P, Q, users, n_items, topn, out_s, out_i);
+    hipLaunchKernelGGL((topn_kernel<L>), dim3((unsigned)nb), dim3(kTopnThreads), lds, st, P, Q, users, n_items, topn, out_s, out_i);
     return hipGetLastError();
 }
 

@@ -40,8 +40,10 @@ WORKLOADS = {
     "cfg2_r1": dict(U=138_493, I=26_744, nnz=20_000_000, k=64, dist="zm", seed=3, q_user=370.0, q_item=40.0),
     # same shape as cfg2 with uniform popularity: no long per-row chains (throughput-bound regime)
     "cfg2_uniform": dict(U=138_493, I=26_744, nnz=20_000_000, k=64, dist="uniform", seed=13),
+    # fitted on the generated extremes like cfg2: heaviest item 232,809 ratings (Netflix Prize: 232,944),
+    # heaviest user 16,761 (17,653), lightest user 17
     "cfg3_netflix": dict(U=480_189, I=17_770, nnz=100_000_000, k=128, dist="zm", seed=4,
-                         q_user=800.0, q_item=12.0),
+                         q_user=100.0, q_item=24.0),
     "cfg4_powerlaw": dict(U=10_000_000, I=1_000_000, nnz=1_000_000_000, k=256, dist="zm", seed=5,
                           s_user=1.1, s_item=1.1, q_user=2000.0, q_item=200.0),
 }
