@@ -54,11 +54,11 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
     using f4 = __attribute__((ext_vector_type(4))) float;
     f4 q = {rq.x, rq.y, rq.z, rq.w};
     if constexpr (L == 16)
-        asm volatile(MFSGD_RUN_LOOP_ASM_TEXT("") MFSGD_RUN_LOOP_ASM_OPERANDS);
+        asm volatile(MFSGD_RUN_LOOP_ASM_TEXT("", MFSGD_SFMA_V) MFSGD_RUN_LOOP_ASM_OPERANDS);
     else if constexpr (L == 32)
-        asm volatile(MFSGD_RUN_LOOP_ASM_TEXT(MFSGD_SWAP_ADD16) MFSGD_RUN_LOOP_ASM_OPERANDS);
+        asm volatile(MFSGD_RUN_LOOP_ASM_TEXT(MFSGD_SWAP_ADD16, MFSGD_SFMA_V) MFSGD_RUN_LOOP_ASM_OPERANDS);
     else
-        asm volatile(MFSGD_RUN_LOOP_ASM_TEXT(MFSGD_SWAP_ADD16 MFSGD_SWAP_ADD32) MFSGD_RUN_LOOP_ASM_OPERANDS);
+        asm volatile(MFSGD_RUN_LOOP_ASM_TEXT(MFSGD_BCAST_ADD64, MFSGD_SFMA_S) MFSGD_RUN_LOOP_ASM_OPERANDS);
     rq = make_float4(q[0], q[1], q[2], q[3]);
 }
 
@@ -72,11 +72,11 @@ __device__ __forceinline__ void solo_chain_asm(const float4 rq, const unsigned e
     using f4 = __attribute__((ext_vector_type(4))) float;
     const f4 q = {rq.x, rq.y, rq.z, rq.w};
     if constexpr (L == 16)
-        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT("") MFSGD_SOLO_CHAIN_OPERANDS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT("", MFSGD_SFMA_V) MFSGD_SOLO_CHAIN_OPERANDS);
     else if constexpr (L == 32)
-        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_SWAP_ADD16) MFSGD_SOLO_CHAIN_OPERANDS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_SWAP_ADD16, MFSGD_SFMA_V) MFSGD_SOLO_CHAIN_OPERANDS);
     else
-        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_SWAP_ADD16 MFSGD_SWAP_ADD32) MFSGD_SOLO_CHAIN_OPERANDS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_BCAST_ADD64, MFSGD_SFMA_S) MFSGD_SOLO_CHAIN_OPERANDS);
 }
 // Returns false if it gave up waiting for the chain wave (bounded polling; cannot happen with a
 // schedule the packer built -- the bound only keeps a corrupt one from hanging the GPU).

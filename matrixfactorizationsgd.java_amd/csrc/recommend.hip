@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) score_kernel(const float* __restrict__ P,
 
 // ---- fused score + select ----------------------------------------------------------------------------
 constexpr int kTopnFused = 128;    // largest topn the fused kernel takes
-constexpr int kTopnTile = 28672;   // items scored per tile (112 KiB of keys in LDS)
+constexpr int kTopnTile = 14336;   // items scored per tile (56 KiB of keys in LDS: two workgroups per CU)
 constexpr int kTopnCand = 2048;    // candidates kept across tiles (tiles x topn must fit)
 
 // float -> unsigned whose order is the float order (-0 counts as +0, as a comparison would)

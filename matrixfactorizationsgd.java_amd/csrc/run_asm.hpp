@@ -41,8 +41,9 @@
 //   32 / 64 lanes per rating -> s = fma(-lr, dot, lr*r) -> q' = fma(s, p, ce*q), p' = fma(s, q, ce*p)
 //   -> store p'.  The prologue loads step 0; a harmless rewrite of an entry word keeps "one LDS
 //   operation behind the reads" so that every pass can use the same counted wait.
-#define MFSGD_RUN_LOOP_ASM_TEXT(EXTRA) \
+#define MFSGD_RUN_LOOP_ASM_TEXT(EXTRA, SFMA) \
         "v_mov_b32 v138, %[ea]\n\t" \
+        "v_mov_b32 v131, %[lr]\n\t" \
         "v_mov_b32 v139, %[rb]\n\t" \
         "ds_read_b32 v114, v138\n\t" \
         "ds_read_b64 v[116:117], v138 offset:8\n\t" \
@@ -74,7 +75,7 @@
         "ds_read_b64 v[118:119], v138 offset:%c[e1p8]\n\t" \
         "v_add_f32_dpp v132, v132, v132 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
         EXTRA \
-        "v_fma_f32 v130, -%[lr], v132, v116\n\t" \
+        SFMA("116") \
         "v_pk_fma_f32 v[140:141], v[130:131], v[104:105], v[122:123] op_sel_hi:[0,1,1]\n\t" \
         "v_pk_fma_f32 v[142:143], v[130:131], v[106:107], v[124:125] op_sel_hi:[0,1,1]\n\t" \
         "v_pk_fma_f32 v[134:135], v[130:131], v[100:101], v[126:127] op_sel_hi:[0,1,1]\n\t" \
@@ -98,7 +99,7 @@
         "ds_read_b64 v[116:117], v138 offset:%c[e2p8]\n\t" \
         "v_add_f32_dpp v132, v132, v132 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
         EXTRA \
-        "v_fma_f32 v130, -%[lr], v132, v118\n\t" \
+        SFMA("118") \
         "v_pk_fma_f32 v[100:101], v[130:131], v[108:109], v[122:123] op_sel_hi:[0,1,1]\n\t" \
         "v_pk_fma_f32 v[102:103], v[130:131], v[110:111], v[124:125] op_sel_hi:[0,1,1]\n\t" \
         "v_pk_fma_f32 v[134:135], v[130:131], v[140:141], v[126:127] op_sel_hi:[0,1,1]\n\t" \
@@ -116,11 +117,21 @@
 // xor-16 / xor-32 levels of the dot reduction for L = 32 / 64 (see swap_add16 / swap_add32): v133 is free
 #define MFSGD_SWAP_ADD16 "v_mov_b32 v133, v132\n\ts_nop 1\n\tv_permlane16_swap_b32 v132, v133\n\ts_nop 1\n\tv_add_f32 v132, v132, v133\n\t"
 #define MFSGD_SWAP_ADD32 "v_mov_b32 v133, v132\n\ts_nop 1\n\tv_permlane32_swap_b32 v132, v133\n\ts_nop 1\n\tv_add_f32 v132, v132, v133\n\t"
+// Both levels at once for L = 64 (one rating per wave, so the dot is wave-uniform): after the 16-lane
+// reduction every lane of row r holds S_r; row_bcast:15 adds lane 15 of rows 0 / 2 into rows 1 / 3
+// (S0+S1, S2+S3), row_bcast:31 adds lane 31 into rows 2 / 3, so lane 63 holds (S2+S3)+(S0+S1) -- the
+// bits of the contract's tree, addition being commutative -- and a v_readlane broadcasts it.  Two DPP
+// adds and two moves on the dependent chain instead of two five-instruction swap levels.
+#define MFSGD_BCAST_ADD64 "s_nop 1\n\tv_add_f32_dpp v132, v132, v132 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\tv_add_f32_dpp v132, v132, v132 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0\n\tv_readlane_b32 vcc_lo, v132, 63\n\t"
+// s = fma(-lr, dot, lr*r): the dot in v132 (every lane of the group holds it), or -- after
+// MFSGD_BCAST_ADD64 -- in vcc_lo, with lr in v131 (one scalar operand per VALU instruction on gfx9)
+#define MFSGD_SFMA_V(LRR) "v_fma_f32 v130, -%[lr], v132, v" LRR "\n\t"
+#define MFSGD_SFMA_S(LRR) "v_fma_f32 v130, -v131, vcc_lo, v" LRR "\n\t"
 #define MFSGD_RUN_LOOP_ASM_OPERANDS                                                                                   \
     : [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [n] "+s"(pairs)                              \
     : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [e1] "n"(EST), [e2] "n"(2 * EST), [e3] "n"(3 * EST),              \
       [e1p8] "n"(EST + 8), [e2p8] "n"(2 * EST + 8)                                                                     \
-    : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
+    : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
       "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",  \
       "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139",  \
       "v140", "v141", "v142", "v143"
@@ -132,7 +143,7 @@
 // v[100:103] q (updated in place); v[104:107] / v[108:111] p row of the even / odd step (prefetched
 // a step ahead); v[116:117] / v[118:119] {lr*r, next slots} of the even / odd step; v113 p address;
 // v[120:121] chunk products, v132 dot, v[122:125] c*q, v130 s.
-#define MFSGD_SOLO_CHAIN_HALF(P0, P1, P2, P3, N0, N1, N2, N3, ELRR, ESLOT, NEXTE, OFF_NEXT, OFF_MBOX, EXTRA) \
+#define MFSGD_SOLO_CHAIN_HALF(P0, P1, P2, P3, N0, N1, N2, N3, ELRR, ESLOT, NEXTE, OFF_NEXT, OFF_MBOX, EXTRA, SFMA) \
         "s_waitcnt lgkmcnt(1)\n\t" \
         "v_pk_mul_f32 v[120:121], v[" P0 ":" P1 "], v[100:101]\n\t" \
         "v_pk_fma_f32 v[120:121], v[" P2 ":" P3 "], v[102:103], v[120:121]\n\t" \
@@ -149,7 +160,7 @@
         "s_nop 1\n\t" \
         "v_add_f32_dpp v132, v132, v132 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
         EXTRA \
-        "v_fma_f32 v130, -%[lr], v132, v" ELRR "\n\t" \
+        SFMA(ELRR) \
         "v_pk_fma_f32 v[100:101], v[130:131], v[" P0 ":" P1 "], v[122:123] op_sel_hi:[0,1,1]\n\t" \
         "v_pk_fma_f32 v[102:103], v[130:131], v[" P2 ":" P3 "], v[124:125] op_sel_hi:[0,1,1]\n\t" \
         "s_sub_u32 %[n], %[n], 1\n\t" \
@@ -157,8 +168,9 @@
         "s_cmp_eq_u32 %[n], 0\n\t"
 
 // `ea` = LDS byte address of the header entry; n >= 1 steps.
-#define MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA) \
+#define MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA, SFMA) \
         "v_mov_b32 v138, %[ea]\n\t" \
+        "v_mov_b32 v131, %[lr]\n\t" \
         "v_mov_b32 v139, %[rb]\n\t" \
         "ds_read_b32 v133, v138 offset:4\n\t" \
         "ds_read_b64 v[116:117], v138 offset:16\n\t" \
@@ -173,9 +185,9 @@
         "s_nop 1\n\t" \
         "v_add_u32 v138, 16, v138\n\t" \
         "1:\n\t" \
-        MFSGD_SOLO_CHAIN_HALF("104", "105", "106", "107", "108", "109", "110", "111", "116", "117", "118:119", "16", "8", EXTRA) \
+        MFSGD_SOLO_CHAIN_HALF("104", "105", "106", "107", "108", "109", "110", "111", "116", "117", "118:119", "16", "8", EXTRA, SFMA) \
         "s_cbranch_scc1 2f\n\t" \
-        MFSGD_SOLO_CHAIN_HALF("108", "109", "110", "111", "104", "105", "106", "107", "118", "119", "116:117", "32", "24", EXTRA) \
+        MFSGD_SOLO_CHAIN_HALF("108", "109", "110", "111", "104", "105", "106", "107", "118", "119", "116:117", "32", "24", EXTRA, SFMA) \
         "v_add_u32 v138, 32, v138\n\t" \
         "s_cbranch_scc0 1b\n\t" \
         "2:\n\t" \
@@ -185,7 +197,7 @@
     : [n] "+s"(n)                                                                                                      \
     : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [c2] "s"(c2), [q0] "v"(q[0]), [q1] "v"(q[1]), [q2] "v"(q[2]),     \
       [q3] "v"(q[3])                                                                                                   \
-    : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
+    : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
       "v113", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v130", "v131", "v132",  \
       "v133", "v138", "v139"
 

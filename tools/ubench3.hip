@@ -17,16 +17,23 @@
 #endif
 #define SWAP16 "v_mov_b32 v133, v132\n\ts_nop 1\n\tv_permlane16_swap_b32 v132, v133\n\ts_nop 1\n\tv_add_f32 v132, v132, v133\n\t"
 #define SWAP32 "v_mov_b32 v133, v132\n\ts_nop 1\n\tv_permlane32_swap_b32 v132, v133\n\ts_nop 1\n\tv_add_f32 v132, v132, v133\n\t"
+#define SFMA MFSGD_SFMA_V
 #if LG == 16
 #define EXTRA ""
 #elif LG == 32
 #define EXTRA SWAP16
 #else
+#ifdef OLD64
 #define EXTRA SWAP16 SWAP32
+#else
+#define EXTRA MFSGD_BCAST_ADD64
+#undef SFMA
+#define SFMA MFSGD_SFMA_S
+#endif
 #endif
 
 constexpr int ROWB = 16 * LG;
-constexpr int NSTEP = (LG == 64 ? 120 : 300), NROWS = NSTEP + 2;  // p rows 0..NSTEP-1, q row NSTEP, zero row NSTEP+1
+constexpr int NSTEP = (LG == 64 ? 120 : LG == 32 ? 200 : 300), NROWS = NSTEP + 2;  // p rows 0..NSTEP-1, q row NSTEP, zero row NSTEP+1
 constexpr int ENT_OFF = NROWS * ROWB;          // entries behind the rows
 constexpr int GS = 64 / LG;                    // slots per step of the (old) run loop
 constexpr int RUN_OFF = ENT_OFF + (NSTEP + 2) * 16;  // mode 3: run-loop entries, NSTEP + 2 steps x GS x 16 bytes
@@ -56,12 +63,12 @@ __global__ void __launch_bounds__(128) k(const float* rows_in, const uint32_t* e
         const unsigned ea = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + RUN_OFF) + g * 16;
         int pairs = n_steps / 2;
         constexpr int EST = GS * 16;
-        asm volatile(MFSGD_RUN_LOOP_ASM_TEXT(EXTRA) MFSGD_RUN_LOOP_ASM_OPERANDS);
+        asm volatile(MFSGD_RUN_LOOP_ASM_TEXT(EXTRA, SFMA) MFSGD_RUN_LOOP_ASM_OPERANDS);
         if (g == 0) *(f4*)(smem + qaddr) = q;
     } else if (wave == 0 && mode != 2) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 q = *(const f4*)(smem + NSTEP * ROWB + (lane % LG) * 16);
-        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA) MFSGD_SOLO_CHAIN_OPERANDS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA, SFMA) MFSGD_SOLO_CHAIN_OPERANDS);
     } else if (wave == 1 && (mode == 0 || mode == 2)) {
         int spins = 1 << 20;
         asm volatile(MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_OPERANDS);
