@@ -663,10 +663,29 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
         }
         h->parts.clear();
         h->have_ratings = false;
-        for (int64_t j = 0; j < nnz; ++j)
-            if (u[j] < 0 || u[j] >= h->cfg.n_users || i[j] < 0 || i[j] >= h->cfg.n_items)
+        {
+            // range check, on the host threads: first offending rating, if any
+            int nt = h->cfg.host_threads > 0 ? h->cfg.host_threads : (int)std::thread::hardware_concurrency();
+            nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(nt, 64), nnz >> 16));
+            std::vector<int64_t> first_bad((size_t)nt, nnz);
+            auto scan = [&](int t) {
+                const int64_t lo = nnz * t / nt, hi = nnz * (t + 1) / nt;
+                const int32_t nu = h->cfg.n_users, ni = h->cfg.n_items;
+                for (int64_t j = lo; j < hi; ++j)
+                    if ((uint32_t)u[j] >= (uint32_t)nu || (uint32_t)i[j] >= (uint32_t)ni) {
+                        first_bad[(size_t)t] = j;
+                        return;
+                    }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back(scan, t);
+            scan(0);
+            for (auto& t : th) t.join();
+            const int64_t j = *std::min_element(first_bad.begin(), first_bad.end());
+            if (j < nnz)
                 return fail(h, MFSGD_ERR_INVALID_ARG, "set_ratings: rating " + std::to_string(j) + " has (u,i) = (" +
                                                           std::to_string(u[j]) + "," + std::to_string(i[j]) + ") out of range");
+        }
         lap("release + range check");
         const int G = h->n_parts;
         h->parts.resize((size_t)G);
@@ -774,19 +793,50 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
     }
 }
 
+// Seeds P (stream position of row u: (u_offset + u) * k) and, for single-partition handles with with_q, Q
+// (row i: (n_users + i) * k).  On the device when there is one (a kernel per matrix; nothing crosses PCIe);
+// on the host otherwise (host-only callers: the factors are uploaded when the first compute call comes).
+static int seed_factors(mfsgd_handle* h, int64_t seed, int64_t u_offset, bool with_q) {
+    const int k = h->cfg.k, kp = h->geo.kp;
+    const float scale = (float)(1.0 / std::sqrt((double)k));
+    release_device_factors(h);
+    h->where = mfsgd_handle::Where::None;
+    if (ensure_device(h) == MFSGD_OK) {
+        int rc;
+        if ((rc = dev_alloc(h, h->dP, sizeof(float) * (size_t)h->cfg.n_users * kp))) return rc;
+        HIPCHK(h, launch_init_rows(static_cast<float*>(h->dP.p), h->cfg.n_users, k, kp, seed, (unsigned long long)u_offset * (unsigned long long)k,
+                                   scale, h->stream));
+        if (with_q) {
+            if ((rc = dev_alloc(h, h->dQ, sizeof(float) * (size_t)h->cfg.n_items * kp))) return rc;
+            HIPCHK(h, launch_init_rows(static_cast<float*>(h->dQ.p), h->cfg.n_items, k, kp, seed,
+                                       (unsigned long long)h->cfg.n_users * (unsigned long long)k, scale, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::vector<float>().swap(h->hP);
+        std::vector<float>().swap(h->hQ);
+        h->where = mfsgd_handle::Where::Device;
+        return MFSGD_OK;
+    }
+    h->err.clear();  // no device: not an error for this call
+    h->hP.assign((size_t)h->cfg.n_users * kp, 0.0f);
+    JRandom g(seed);
+    g.skip((uint64_t)u_offset * (uint64_t)k);
+    fill_rows(g, h->hP.data(), h->cfg.n_users, k, kp, scale);
+    h->hQ.clear();
+    if (with_q) {
+        h->hQ.assign((size_t)h->cfg.n_items * kp, 0.0f);
+        JRandom gq(seed);
+        gq.skip((uint64_t)h->cfg.n_users * (uint64_t)k);
+        fill_rows(gq, h->hQ.data(), h->cfg.n_items, k, kp, scale);
+    }
+    h->where = mfsgd_handle::Where::Host;
+    return MFSGD_OK;
+}
+
 int mfsgd_init_p_offset(mfsgd_handle* h, int64_t seed, int64_t u_offset) {
     if (!h || u_offset < 0) return fail(h, MFSGD_ERR_INVALID_ARG, "init_p_offset: bad argument");
     try {
-        const int k = h->cfg.k, kp = h->geo.kp;
-        const float scale = (float)(1.0 / std::sqrt((double)k));
-        release_device_factors(h);
-        h->hP.assign((size_t)h->cfg.n_users * kp, 0.0f);
-        JRandom g(seed);
-        g.skip((uint64_t)u_offset * (uint64_t)k);
-        fill_rows(g, h->hP.data(), h->cfg.n_users, k, kp, scale);
-        h->hQ.clear();
-        h->where = mfsgd_handle::Where::Host;
-        return MFSGD_OK;
+        return seed_factors(h, seed, u_offset, false);
     } catch (const std::bad_alloc&) {
         return fail(h, MFSGD_ERR_OOM, "init_p_offset: out of host memory");
     }
@@ -794,17 +844,8 @@ int mfsgd_init_p_offset(mfsgd_handle* h, int64_t seed, int64_t u_offset) {
 
 int mfsgd_init_factors(mfsgd_handle* h, int64_t seed) {
     if (!h) return MFSGD_ERR_INVALID_ARG;
-    int rc = mfsgd_init_p_offset(h, seed, 0);
-    if (rc) return rc;
-    if (h->n_parts > 1) return MFSGD_OK;  // Q lives in caller-owned blocks
     try {
-        const int k = h->cfg.k, kp = h->geo.kp;
-        const float scale = (float)(1.0 / std::sqrt((double)k));
-        h->hQ.assign((size_t)h->cfg.n_items * kp, 0.0f);
-        JRandom g(seed);
-        g.skip((uint64_t)h->cfg.n_users * (uint64_t)k);
-        fill_rows(g, h->hQ.data(), h->cfg.n_items, k, kp, scale);
-        return MFSGD_OK;
+        return seed_factors(h, seed, 0, h->n_parts == 1);  // n_parts > 1: Q lives in caller-owned blocks
     } catch (const std::bad_alloc&) {
         return fail(h, MFSGD_ERR_OOM, "init_factors: out of host memory");
     }

@@ -997,6 +997,47 @@ hipError_t sse_L(int W, const CellLaunch& a, int n_cells, hipStream_t st) {
     }
 }
 
+// Factor initialisation on the device: java.util.Random(seed).nextFloat() * scale, row-major, the stream
+// position of row x being first_pos + x * k -- the 48-bit LCG jumped to that position per row (the same
+// doubling recurrence as JRandom::skip), then k sequential draws.  Integer work plus one exact division and
+// one multiply per element: the bits csrc/jrandom.hpp and the oracle produce.
+__global__ void __launch_bounds__(256) init_rows_kernel(float* __restrict__ dst, const long long rows, const int k,
+                                                        const int kp, const unsigned long long s0,
+                                                        const unsigned long long first_pos, const float scale) {
+    constexpr unsigned long long kMult = 0x5DEECE66DULL, kAdd = 0xBULL, kMask = (1ULL << 48) - 1;
+    for (long long row = (long long)blockIdx.x * 256 + threadIdx.x; row < rows; row += (long long)gridDim.x * 256) {
+        unsigned long long n = first_pos + (unsigned long long)row * (unsigned long long)k;
+        unsigned long long acc_a = 1, acc_c = 0, cur_a = kMult, cur_c = kAdd;
+        while (n) {
+            if (n & 1) {
+                acc_a = (acc_a * cur_a) & kMask;
+                acc_c = (acc_c * cur_a + cur_c) & kMask;
+            }
+            cur_c = ((cur_a + 1) * cur_c) & kMask;
+            cur_a = (cur_a * cur_a) & kMask;
+            n >>= 1;
+        }
+        unsigned long long s = (acc_a * s0 + acc_c) & kMask;
+        float* out = dst + (size_t)row * kp;
+        for (int f = 0; f < k; ++f) {
+            s = (s * kMult + kAdd) & kMask;
+            const int v = (int)(unsigned)(s >> 24);  // next(24)
+            out[f] = (float)v / 16777216.0f * scale;
+        }
+        for (int f = k; f < kp; ++f) out[f] = 0.0f;
+    }
+}
+
+hipError_t launch_init_rows(float* dst, long long rows, int k, int kp, long long seed, unsigned long long first_pos, float scale,
+                            hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    const unsigned long long s0 = ((unsigned long long)seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1);
+    long long g = (rows + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(init_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, dst, rows, k, kp, s0, first_pos, scale);
+    return hipGetLastError();
+}
+
 // Diagnostic: workgroups that hold a whole CU's LDS and spin for `ticks` of the 100 MHz clock.
 __global__ void __launch_bounds__(64) occupy_kernel(const unsigned long long ticks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -42,6 +42,10 @@ hipError_t launch_reduce_sse(const double* partial, int64_t n, double* out, hipS
 hipError_t launch_predict(int L, const float* P, const float* Q, const int32_t* u, const int32_t* i,
                           float* out, int64_t n, hipStream_t st);
 
+// rows x kp floats: java.util.Random(seed) draws first_pos + row * k ... scaled, zero padded (device-side seeding).
+hipError_t launch_init_rows(float* dst, long long rows, int k, int kp, long long seed, unsigned long long first_pos, float scale,
+                            hipStream_t st);
+
 // Diagnostic (tests): `workgroups` one-wave workgroups, each holding lds_bytes of LDS, spin for `ticks` x 10 ns.
 hipError_t launch_occupy(int workgroups, int lds_bytes, unsigned long long ticks, hipStream_t st);
 
