@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--parts-per-rank", type=int, default=0, help="DSGD: item partitions a rank holds at a time (0 = 1)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debugging: run ONE rank of an N-GPU DSGD job on one "
                     "GPU without communication (per-rank compute time of that job)")
+    ap.add_argument("--selftest-native-ring", type=int, default=0, metavar="PARTS", help="debugging, one GPU: run the N > 1 "
+                    "code path of this file (global plan, ring under the C-ABI, its timing) with PARTS item partitions and an "
+                    "RCCL self-ring on this rank alone")
     ap.add_argument("--round-launch", action="store_true", help="one kernel per round instead of the persistent epoch kernel")
     args = ap.parse_args()
 
@@ -162,17 +165,21 @@ def main():
     # partitions of one rank share its users, so they are trained one after another; more than
     # one per rank only makes the schedules smaller
     ppr = args.parts_per_rank if args.parts_per_rank > 0 else 1
-    n_parts = vworld * ppr if vworld > 1 else 0
+    selftest = args.selftest_native_ring if world == 1 and not emu and args.selftest_native_ring > 1 else 0
+    if selftest:
+        ppr = selftest
+    n_parts = vworld * ppr if (vworld > 1 or selftest) else 0
     m = mfsgd_amd.MatrixFactorizationSGD(w["U"], w["I"], k, LR, LAM, SEED, device=local_rank, blocks=args.blocks,
                                          waves=args.waves, n_parts=n_parts,
                                          host_threads=host_threads(), flags=flags)
     t0 = time.time()
-    native = world > 1 and args.ring == "native" and args.backend != "gloo"
+    native = (world > 1 and args.ring == "native" and args.backend != "gloo") or bool(selftest)
     if native:
         # the global partitioner: item partitions balanced by the GLOBAL rating counts (users are already
         # dealt out evenly: every rank brought the same number of ratings)
         deg_i = torch.from_numpy(np.bincount(w["i"], minlength=w["I"]).astype(np.int64))
-        dist.all_reduce(deg_i)
+        if dist is not None:
+            dist.all_reduce(deg_i)
         _, item_part = mfsgd_amd.dsgd_plan(np.ones(world, np.int64), deg_i.numpy(), n_parts)
         m.set_item_partition(item_part)
     m.set_ratings(w["u"], w["i"], w["r"])
@@ -194,7 +201,8 @@ def main():
             obj = [NativeDSGD.unique_id() if rank == 0 else None]
         except Exception as e:  # noqa: BLE001
             obj, why = [None], repr(e)
-        dist.broadcast_object_list(obj, src=0)
+        if dist is not None:
+            dist.broadcast_object_list(obj, src=0)
         m.init_p_offset(SEED, rank * w["U"])
         if obj[0] is not None:
             try:
@@ -202,15 +210,22 @@ def main():
             except Exception as e:  # noqa: BLE001
                 why = repr(e)
         ok = torch.tensor([1 if d_native is not None else 0], dtype=torch.int32)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if dist is not None:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if not bool(ok[0]):
+            if selftest:
+                raise SystemExit(f"--selftest-native-ring: the ring did not come up: {why}")
             log(f"rank {rank}: the ring under the C-ABI did not come up ({why or 'another rank failed'}); "
                 "using the torch.distributed harness instead (see config.parallelism)")
             if d_native is not None:
                 d_native.close()
             d_native, native, ring_note = None, False, "-torch-ring-fallback"
 
-    if vworld == 1:
+    def _barrier():
+        if dist is not None:
+            dist.barrier()
+
+    if vworld == 1 and not selftest:
         m.init_factors(SEED)
         rmse0 = m.rmse()  # also moves everything to the device
         for _ in range(args.warmup):
@@ -229,16 +244,17 @@ def main():
         rmse0 = d.rmse()
         d.train(args.warmup, rmse=False)
         torch.cuda.synchronize()
-        dist.barrier()
+        _barrier()
         torch.cuda.synchronize()
         t_wall0 = time.perf_counter()
         d.train(args.steps, rmse=False)  # returns when the compute and the communication stream are idle
         torch.cuda.synchronize()
-        dist.barrier()
+        _barrier()
         torch.cuda.synchronize()
         wall_s = time.perf_counter() - t_wall0
         tmax = torch.tensor([wall_s], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if dist is not None:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed_s = float(tmax[0])
         dev_ms = elapsed_s * 1e3
         launches = launches_per_epoch * args.steps
@@ -337,7 +353,7 @@ def main():
             "sum_round_steps": sum(i["sum_round_steps"] for i in infos),
             "blocks": infos[0]["blocks"], "waves": infos[0]["waves"],
             "parts_per_rank": ppr, "emulated_world": emu,
-            "parallelism": "single" if world == 1 else f"dsgd{world}" + ("-gloo-rehearsal" if args.backend == "gloo" else "")
+            "parallelism": (f"selftest-1rank-{selftest}parts" if selftest else "single") if world == 1 else f"dsgd{world}" + ("-gloo-rehearsal" if args.backend == "gloo" else "")
                            + ("-native-rccl-ring" if native else "") + ring_note,
         },
         "rmse_before": rmse0,
@@ -346,7 +362,7 @@ def main():
         "wall_ms": wall_s * 1e3,
         "roofline": roofline,
     }
-    if world == 1 and not emu:
+    if world == 1 and not emu and not selftest:
         # What a caller of train(u, i, r, 10) with HOST arrays sees end to end on a fresh handle: hashing and
         # uploading the triples, building the schedule (device ingest + device packer), seeding the factors,
         # 10 epochs AND the RMSE pass after each (the Java train() returns per-epoch RMSE).  Never `value`.
