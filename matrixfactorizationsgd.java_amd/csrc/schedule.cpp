@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <iterator>
 #include <numeric>
@@ -395,8 +396,25 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     }
     lap(on_device ? "degrees (device)" : "degrees");
     std::vector<int32_t> ubin, ibin;
-    lpt_assign(degu, B * W, ubin);
-    lpt_assign(degi, B * W, ibin);
+    {
+        // users and items are independent: one thread each (the LPT itself is a sequential heap walk)
+        std::exception_ptr failed_u;
+        std::thread tu([&]() {
+            try {
+                lpt_assign(degu, B * W, ubin);
+            } catch (...) {
+                failed_u = std::current_exception();  // no exception may leave a thread
+            }
+        });
+        try {
+            lpt_assign(degi, B * W, ibin);
+        } catch (...) {
+            tu.join();
+            throw;
+        }
+        tu.join();
+        if (failed_u) std::rethrow_exception(failed_u);
+    }
     lap("LPT partition");
     // fine bin f -> block f % B, sub-group f / B
 
