@@ -385,19 +385,26 @@ def test_device_ingest_and_device_packer_build_the_same_schedule(mf):
         _same_schedule(mf, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"], expect_packed=packed)
 
 
-def test_device_packer_fuzz(mf):
+def test_device_packer_fuzz(mf, oracle):
     """Random small problems (sizes, skew, repeated pairs, every k and explicit B / W) through the device
-    packer: byte-identical to the host packer wherever the device takes the job."""
+    packer: byte-identical to the host packer wherever the device takes the job -- and, independently of
+    the host packer, a conflict-free permutation by the oracle's checker that trains bit-exactly."""
+    from mfsgd_amd import _lib
     from tests.dsgd_common import fuzz_cases
 
     n_packed = n = 0
     for c in fuzz_cases(80, seed=4321, max_ratings=4000):
         try:
-            n_packed += _same_schedule(mf, c["U"], c["I"], c["k"], c["u"], c["i"], c["r"], blocks=c["blocks"], waves=c["waves"])
+            packed = _same_schedule(mf, c["U"], c["I"], c["k"], c["u"], c["i"], c["r"], blocks=c["blocks"], waves=c["waves"])
         except mf.MfsgdError as e:
             assert e.code == -7, e
             continue
         n += 1
+        n_packed += packed
+        if packed and n_packed % 4 == 0:  # _run checks the exported order with mfo_check_block_schedule and replays it
+            _, info = _run(mf, oracle, c["U"], c["I"], c["k"], c["u"], c["i"], c["r"], epochs=2, lr=c["lr"], lam=c["lam"],
+                           blocks=c["blocks"], waves=c["waves"], flags=_lib.FLAG_DEVICE_INGEST)
+            assert info["device_ingest"] == 2
     assert n >= 60 and n_packed >= n // 2, (n, n_packed)
 
 
