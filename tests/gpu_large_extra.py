@@ -22,6 +22,17 @@ import mfsgd_amd as mf  # noqa: E402
 from tests.oracle_bind import Oracle  # noqa: E402
 from tests.test_gpu_parity import _virtual_dsgd  # noqa: E402
 
+import threading  # noqa: E402
+
+
+def _heartbeat():  # the GPU pool takes seven silent minutes for a hang
+    t = time.time()
+    while True:
+        time.sleep(60)
+        print(f"  ... {time.time() - t:.0f} s", flush=True)
+
+
+threading.Thread(target=_heartbeat, daemon=True).start()
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.125
 t0 = time.time()
 w = mf.synth.workload("cfg4_powerlaw", scale)
