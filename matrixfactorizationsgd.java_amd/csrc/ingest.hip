@@ -315,16 +315,20 @@ fail:
     return rc;
 }
 
-int pack_emit_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
-                 int64_t n_steps, DevicePacked* out) {
-    Ctx* c = static_cast<Ctx*>(vctx);
+int emit_common(Ctx* c, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
+                int64_t n_steps, const MixedPieces* host, DevicePacked* out) {
     if (!c->d_info || !out) return -1;
     PackArgs a = c->args;
     uint32_t *d_ro = nullptr, *d_eo = nullptr, *d_rows = nullptr;
     long long *d_oo = nullptr, *d_order = nullptr;
     Entry* d_ent = nullptr;
+    void* staged[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const size_t nc = (size_t)c->n_cells;
     std::vector<long long> oo(ord_off, ord_off + nc);
+    auto stage = [&](int slot, const void* p, size_t bytes) -> bool {
+        if (bytes == 0) return true;
+        return hipMalloc(&staged[slot], bytes) == hipSuccess && hipMemcpy(staged[slot], p, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
     ING_CHK(hipMalloc(&d_ro, 4 * nc));
     ING_CHK(hipMalloc(&d_eo, 4 * nc));
     ING_CHK(hipMalloc(&d_oo, 8 * nc));
@@ -343,8 +347,24 @@ int pack_emit_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_off, c
     a.entries = d_ent;
     a.order = d_order;
     ING_CHK(launch_pack(a, c->n_cells, (hipStream_t)0));
+    if (host) {
+        // what the host packed: three staging arrays and their segment lists, then one copy kernel each
+        if (!stage(0, host->rows.data(), host->rows.size() * 4) || !stage(1, host->seg_rows.data(), host->seg_rows.size() * sizeof(MixedSegment)) ||
+            !stage(2, host->entries.data(), host->entries.size() * sizeof(Entry)) ||
+            !stage(3, host->seg_entries.data(), host->seg_entries.size() * sizeof(MixedSegment)) ||
+            !stage(4, host->order.data(), host->order.size() * 8) ||
+            !stage(5, host->seg_order.data(), host->seg_order.size() * sizeof(MixedSegment))) {
+            (void)hipGetLastError();
+            goto fail;
+        }
+        ING_CHK(launch_scatter(d_rows, staged[0], static_cast<const MixedSegment*>(staged[1]), (long long)host->seg_rows.size(), 4, (hipStream_t)0));
+        ING_CHK(launch_scatter(d_ent, staged[2], static_cast<const MixedSegment*>(staged[3]), (long long)host->seg_entries.size(), 16, (hipStream_t)0));
+        ING_CHK(launch_scatter(d_order, staged[4], static_cast<const MixedSegment*>(staged[5]), (long long)host->seg_order.size(), 8, (hipStream_t)0));
+    }
     ING_CHK(hipDeviceSynchronize());
     (void)hipFree(d_ro); (void)hipFree(d_eo); (void)hipFree(d_oo);
+    for (void* p : staged)
+        if (p) (void)hipFree(p);
     out->rows = d_rows;
     out->entries = d_ent;
     out->order = d_order;
@@ -358,7 +378,19 @@ fail:
     if (d_rows) (void)hipFree(d_rows);
     if (d_ent) (void)hipFree(d_ent);
     if (d_order) (void)hipFree(d_order);
+    for (void* p : staged)
+        if (p) (void)hipFree(p);
     return -1;
+}
+
+int pack_emit_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
+                 int64_t n_steps, DevicePacked* out) {
+    return emit_common(static_cast<Ctx*>(vctx), row_off, ent_off, ord_off, n_rows, n_steps, nullptr, out);
+}
+
+int pack_emit_mixed_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
+                       int64_t n_steps, const MixedPieces& host, DevicePacked* out) {
+    return emit_common(static_cast<Ctx*>(vctx), row_off, ent_off, ord_off, n_rows, n_steps, &host, out);
 }
 
 int download_cb(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* entries, int64_t n_entries, int64_t* order,
@@ -371,7 +403,7 @@ int download_cb(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* en
     return 0;
 }
 
-const DeviceIngestExt kExt = {bucket_dev_cb, fetch_sorted_cb, pack_count_cb, pack_emit_cb, download_cb};
+const DeviceIngestExt kExt = {bucket_dev_cb, fetch_sorted_cb, pack_count_cb, pack_emit_cb, pack_emit_mixed_cb, download_cb};
 
 }  // namespace
 

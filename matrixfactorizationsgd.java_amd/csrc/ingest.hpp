@@ -49,6 +49,18 @@ struct DevicePacked {
     void (*release)(void*) = nullptr;
 };
 
+// What the host packed in a mixed build: concatenated pieces and where each goes in the final arrays
+// (element offsets: uint32 words of rows[], Entry records, int64 order positions).
+struct MixedSegment {
+    uint64_t dst, src, n;
+};
+struct MixedPieces {
+    std::vector<uint32_t> rows;
+    std::vector<Entry> entries;
+    std::vector<int64_t> order;
+    std::vector<MixedSegment> seg_rows, seg_entries, seg_order;
+};
+
 struct DeviceIngestExt {
     // like DeviceIngest::bucket, but the sorted indices stay on the device (only bptr comes back)
     int (*bucket_dev)(void* ctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
@@ -61,6 +73,9 @@ struct DeviceIngestExt {
     // EMIT pass at the offsets the caller derived from the COUNT pass (per cell, B*B entries each)
     int (*pack_emit)(void* ctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
                      int64_t n_steps, DevicePacked* out) = nullptr;
+    // EMIT for the cells whose row_off is not 0xFFFFFFFF, then the host-packed pieces scattered to their places
+    int (*pack_emit_mixed)(void* ctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
+                           int64_t n_steps, const MixedPieces& host, DevicePacked* out) = nullptr;
     // device -> host copies of what emit() produced (debug / get_order); any pointer may be null
     int (*download)(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* entries, int64_t n_entries, int64_t* order,
                     int64_t n) = nullptr;

@@ -23,6 +23,7 @@
 
 #include <cstdint>
 
+#include "ingest.hpp"
 #include "pack.hpp"
 
 namespace mfsgd {
@@ -106,6 +107,7 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
     int* sub_info = reinterpret_cast<int*>(wbase + (size_t)kWaves * wave_bytes);  // [x][0..3] = ns, nr, nsolo, units
     int* misc = sub_info + WW * 4;                                                  // [0] status, [1] nu, [2] ni
 
+    if (a.emit && a.row_off[cell] == 0xFFFFFFFFu) return;  // mixed build: the host packed this cell
     const long long lo = a.bptr[cell * WW], hi = a.bptr[(cell + 1) * WW];
     const int m = (int)(hi - lo);
     PackCellInfo info{};
@@ -619,6 +621,24 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
         idle_general(stepcur);
         idle_general(stepcur + 1);
     }
+}
+
+// dst[seg.dst + x] = src[seg.src + x] for x < seg.n, elements of `elem` bytes (a multiple of 4): one workgroup
+// per segment.  Places the pieces the host packed in a mixed build.
+__global__ void __launch_bounds__(256) scatter_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src,
+                                                      const MixedSegment* __restrict__ segs, const int words_per_elem) {
+    const MixedSegment s = segs[blockIdx.x];
+    unsigned* d = dst + s.dst * words_per_elem;
+    const unsigned* q = src + s.src * words_per_elem;
+    const unsigned long long nw = s.n * (unsigned long long)words_per_elem;
+    for (unsigned long long x = threadIdx.x; x < nw; x += 256) d[x] = q[x];
+}
+
+hipError_t launch_scatter(void* dst, const void* src, const MixedSegment* segs, long long n_segs, int elem_bytes, hipStream_t st) {
+    if (n_segs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)n_segs), dim3(256), 0, st, static_cast<unsigned*>(dst),
+                       static_cast<const unsigned*>(src), segs, elem_bytes / 4);
+    return hipGetLastError();
 }
 
 size_t pack_lds_bytes(const PackArgs& a) {

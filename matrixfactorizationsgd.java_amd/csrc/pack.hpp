@@ -35,6 +35,9 @@ struct PackArgs {
     long long* order;        // EMIT out
 };
 
+struct MixedSegment;
+// one workgroup per segment: dst[seg.dst + x] = src[seg.src + x], x < seg.n, elements of elem_bytes (multiple of 4)
+hipError_t launch_scatter(void* dst, const void* src, const MixedSegment* segs, long long n_segs, int elem_bytes, hipStream_t st);
 size_t pack_lds_bytes(const PackArgs& a);
 hipError_t launch_pack(const PackArgs& a, long long n_cells, hipStream_t st);
 

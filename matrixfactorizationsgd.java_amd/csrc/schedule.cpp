@@ -83,6 +83,10 @@ struct CellOut {
     uint32_t nu = 0, ni = 0, n_steps = 0;
     int64_t crit = 0;
     bool has_run = false;
+    // sizes, valid also when the arrays above are empty because the DEVICE holds (or will write) the data
+    uint32_t n_rows = 0;
+    int64_t n_order = 0;
+    bool dev = false;  // packed by the device packer: rows / entries / order are not here
 };
 
 struct Scratch {
@@ -473,6 +477,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         return -1;
     }
     // ---- the device packer: every cell as a single chunk, same bytes as the host packer below -----
+    std::vector<PackCellInfo> info;  // per cell, from the device's COUNT pass (kept for the mixed mode)
+    std::vector<SubDesc> dsubs;
+    bool have_info = false;
     if (sorted_on_device) {
         const char* why = "";
         const int rc = [&]() -> int {
@@ -495,13 +502,12 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             q.solo_ok = solo_ok;
             for (int64_t cc = 0; cc < ncell; ++cc)
                 q.max_cell_nnz = std::max(q.max_cell_nnz, bptr[(size_t)((cc + 1) * WW)] - bptr[(size_t)(cc * WW)]);
-            std::vector<PackCellInfo> info;
-            std::vector<SubDesc> dsubs;
             int prc = ext->pack_count(prm.ingest->ctx, q, info, dsubs);
             if (prc != 0) {
                 why = "the rating set is outside the kernel's limits (cell size, ranks, LDS)";
                 return prc;
             }
+            have_info = ext->pack_emit_mixed != nullptr;  // from here on a refusal means "mixed mode", not "host"
             lap("  device pack: count");
             // every cell must fit the training kernel's LDS image as ONE chunk (chunking is the host's job)
             int64_t max_s = min_sched, max_r = min_rows, tot_rows = 0, tot_steps = 0;
@@ -598,7 +604,10 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             err = "build_schedule: could not fetch the bucket order from the device";
             return -1;
         }
-        if (trace) std::fprintf(stderr, "[schedule]   device pack %s: %s\n", rc == 1 ? "declined" : "FAILED", why);
+        if (rc != 1) have_info = false;
+        if (trace)
+            std::fprintf(stderr, "[schedule]   device pack %s: %s%s\n", rc == 1 ? "declined" : "FAILED", why,
+                         have_info ? " -> mixed mode: the device keeps the cells that fit, the host packs the rest" : "");
         lap("  bucket order to the host");
     }
     std::atomic<int> failed{0};
@@ -747,6 +756,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 o.entries.push_back(make_entry(encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, geo.L), 0.0f, hy.c, hy));
         o.n_steps = stepcur + 2;
         o.crit = crit;
+        o.n_rows = (uint32_t)nrows;
+        o.n_order = m;
         return true;
     };
     auto load_cell = [&](int64_t c, std::vector<RawRat>& sel) {
@@ -798,6 +809,23 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     o.subs.assign((size_t)WW, SubDesc{0, 0});
                     continue;
                 }
+                if (have_info) {
+                    // mixed mode: a cell the device packed as one chunk stays there (only its sizes come here)
+                    const PackCellInfo& ci = info[(size_t)c];
+                    const int nrows = (int)(ci.nu + ci.ni);
+                    if (ci.status == 0 && addressable(nrows) && rows_bytes_for(geo, nrows) + 2 * min_sched <= avail) {
+                        o.subs.assign(dsubs.begin() + c * WW, dsubs.begin() + (c + 1) * WW);
+                        o.nu = ci.nu;
+                        o.ni = ci.ni;
+                        o.n_steps = ci.n_steps;
+                        o.crit = ci.crit;
+                        o.has_run = ci.has_run != 0;
+                        o.n_rows = (uint32_t)nrows;
+                        o.n_order = bptr[(size_t)((c + 1) * WW)] - bptr[(size_t)(c * WW)];
+                        o.dev = true;
+                        continue;
+                    }
+                }
                 load_cell(c, sel);
                 int nu, ni;
                 distinct_rows(sel, sc, nu, ni);
@@ -806,7 +834,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     o = CellOut{};
                     o.nu = (uint32_t)nu;  // kept for the limit search below
                     o.ni = (uint32_t)ni;
-                    o.order.resize(sel.size());
+                    o.n_order = (int64_t)sel.size();
                     oversize[(size_t)c] = 1;
                 }
             }
@@ -850,7 +878,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     const int64_t rb = rows_bytes_for(geo, (int)(o.nu + o.ni));
                     // an unpacked (oversize) cell: guess its steps from its rating count
                     const int64_t sb = oversize[(size_t)c]
-                                           ? sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.order.size() * 2 / G + 2)
+                                           ? sched_bytes_for(geo, W, (int)(o.nu + o.ni), o.n_order * 2 / G + 2)
                                            : sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps);
                     if (sb <= S && rb <= R && !oversize[(size_t)c]) continue;
                     cost += std::max(1.0, std::max((double)sb / (double)S, (double)rb / (double)R));
@@ -971,7 +999,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     {
         int64_t next_desc = ncell;
         auto place = [&](int64_t d, const CellOut& o, uint32_t next) -> bool {
-            if (tot_rows > 0xFFFFFFFFll - (int64_t)o.rows.size() || tot_steps > 0xFFFFFFFFll - o.n_steps) return false;
+            if (tot_rows > 0xFFFFFFFFll - (int64_t)o.n_rows || tot_steps > 0xFFFFFFFFll - o.n_steps) return false;
             CellDesc cdsc{};
             cdsc.row_off = (uint32_t)tot_rows;
             cdsc.ent_off = (uint32_t)tot_steps;
@@ -983,7 +1011,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             by_desc[(size_t)d] = &o;
             for (int x = 0; x < WW; ++x)
                 out.subs[(size_t)(d * WW + x)] = o.subs.empty() ? SubDesc{0, 0} : o.subs[(size_t)x];
-            tot_rows += (int64_t)o.rows.size();
+            tot_rows += (int64_t)o.n_rows;
             tot_steps += o.n_steps;
             if (o.n_steps != 0) {
                 sched_cap = std::max(sched_cap, sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps));
@@ -994,13 +1022,13 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         for (int64_t c = 0; c < ncell; ++c) {
             const std::vector<CellOut>& ex = extra[(size_t)c];
             bool ok = place(c, co[(size_t)c], ex.empty() ? 0u : (uint32_t)next_desc);
-            int64_t nnz_c = (int64_t)co[(size_t)c].order.size(), rows_c = (int64_t)co[(size_t)c].rows.size();
+            int64_t nnz_c = co[(size_t)c].n_order, rows_c = (int64_t)co[(size_t)c].n_rows;
             int64_t crit_c = co[(size_t)c].crit;
             for (size_t x = 0; ok && x < ex.size(); ++x) {
                 ok = place(next_desc, ex[x], x + 1 < ex.size() ? (uint32_t)(next_desc + 1) : 0u);
                 ++next_desc;
-                nnz_c += (int64_t)ex[x].order.size();
-                rows_c = std::max(rows_c, (int64_t)ex[x].rows.size());
+                nnz_c += ex[x].n_order;
+                rows_c = std::max(rows_c, (int64_t)ex[x].n_rows);
                 crit_c += ex[x].crit;
             }
             if (!ok) {
@@ -1028,6 +1056,84 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     }
     out.total_rows = tot_rows;
     out.total_steps = tot_steps;
+    // canonical order: rounds, then blocks; a cell's ratings (all its chunks) are contiguous
+    out.cell_ptr.assign((size_t)ncell + 1, 0);
+    int64_t pos = 0;
+    for (int rd = 0; rd < B; ++rd) {
+        int64_t worst = 0;
+        for (int b = 0; b < B; ++b) {
+            const int64_t c = (int64_t)b * B + (b + rd) % B;
+            out.cell_ptr[(size_t)((int64_t)rd * B + b)] = pos;
+            int64_t crit_c = co[(size_t)c].crit;
+            pos += co[(size_t)c].n_order;
+            for (const CellOut& o : extra[(size_t)c]) {
+                pos += o.n_order;
+                crit_c += o.crit;
+            }
+            worst = std::max(worst, crit_c);
+        }
+        out.sum_round_steps += worst;
+    }
+    out.cell_ptr[(size_t)ncell] = pos;
+    if (pos != n) {
+        err = "build_schedule: internal error, packed " + std::to_string(pos) + " of " + std::to_string(n);
+        return -1;
+    }
+    int64_t n_dev_cells = 0;
+    for (int64_t c = 0; c < ncell; ++c) n_dev_cells += co[(size_t)c].dev ? 1 : 0;
+    if (n_dev_cells > 0) {
+        // ---- mixed finish: the device writes its cells at their final places (EMIT pass), what the host
+        // packed (cells that had to be chunked, cells the kernel could not hold) is scattered behind it
+        MixedPieces mp;
+        std::vector<uint32_t> row_off((size_t)ncell, 0xFFFFFFFFu), ent_off((size_t)ncell, 0u);
+        std::vector<int64_t> ord_off((size_t)ncell, 0);
+        for (int64_t x = 0; x < n_descs; ++x) {
+            const CellOut& o = *by_desc[(size_t)x];
+            const CellDesc& d = out.cells[(size_t)x];
+            if (o.dev) {
+                row_off[(size_t)x] = d.row_off;  // (device cells are first chunks: x < ncell)
+                ent_off[(size_t)x] = d.ent_off;
+                continue;
+            }
+            if (!o.rows.empty()) {
+                mp.seg_rows.push_back({(uint64_t)d.row_off, (uint64_t)mp.rows.size(), (uint64_t)o.rows.size()});
+                mp.rows.insert(mp.rows.end(), o.rows.begin(), o.rows.end());
+            }
+            if (!o.entries.empty()) {
+                mp.seg_entries.push_back({(uint64_t)d.ent_off * G, (uint64_t)mp.entries.size(), (uint64_t)o.entries.size()});
+                mp.entries.insert(mp.entries.end(), o.entries.begin(), o.entries.end());
+            }
+        }
+        for (int64_t x = 0; x < ncell; ++x) {
+            const int64_t rd = x / B, b = x % B;
+            const int64_t c = b * B + (b + rd) % B;
+            int64_t at = out.cell_ptr[(size_t)x];
+            ord_off[(size_t)c] = at;
+            auto piece = [&](const CellOut& o) {
+                if (!o.dev && !o.order.empty()) {
+                    mp.seg_order.push_back({(uint64_t)at, (uint64_t)mp.order.size(), (uint64_t)o.order.size()});
+                    mp.order.insert(mp.order.end(), o.order.begin(), o.order.end());
+                }
+                at += o.n_order;
+            };
+            piece(co[(size_t)c]);
+            for (const CellOut& o : extra[(size_t)c]) piece(o);
+        }
+        lap("  mixed: staging of the host-packed pieces");
+        if (ext->pack_emit_mixed(prm.ingest->ctx, row_off.data(), ent_off.data(), ord_off.data(), tot_rows, tot_steps, mp,
+                                 &out.dev.buf) != 0) {
+            err = "build_schedule: the device packer's EMIT pass failed";
+            return -1;
+        }
+        lap("  mixed: emit + scatter");
+        out.device_packed = true;
+        out.dev_ops = ext;
+        out.device_ingest = true;
+        out.n_rows_words = tot_rows + 4;
+        out.n_entry_recs = tot_steps * G;
+        out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        return 0;
+    }
     out.rows.resize_uninit((size_t)tot_rows + 4);  // +16 B: the staging DMA reads whole 16-byte units
     for (int x = 0; x < 4; ++x) out.rows[(size_t)tot_rows + (size_t)x] = 0u;
     out.entries.resize_uninit((size_t)(tot_steps * G));
@@ -1055,28 +1161,6 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     }
     lap("  copy rows/entries");
     out.order.resize_uninit((size_t)n);
-    out.cell_ptr.assign((size_t)ncell + 1, 0);
-    int64_t pos = 0;
-    for (int rd = 0; rd < B; ++rd) {
-        int64_t worst = 0;
-        for (int b = 0; b < B; ++b) {
-            const int64_t c = (int64_t)b * B + (b + rd) % B;
-            out.cell_ptr[(size_t)((int64_t)rd * B + b)] = pos;
-            int64_t crit_c = co[(size_t)c].crit;
-            pos += (int64_t)co[(size_t)c].order.size();
-            for (const CellOut& o : extra[(size_t)c]) {
-                pos += (int64_t)o.order.size();
-                crit_c += o.crit;
-            }
-            worst = std::max(worst, crit_c);
-        }
-        out.sum_round_steps += worst;
-    }
-    out.cell_ptr[(size_t)ncell] = pos;
-    if (pos != n) {
-        err = "build_schedule: internal error, packed " + std::to_string(pos) + " of " + std::to_string(n);
-        return -1;
-    }
     {
         // the copies, in parallel over (round, block) slots
         std::atomic<int64_t> nslot{0};
@@ -1091,7 +1175,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     auto append = [&](const CellOut& o) {
                         if (!o.order.empty())
                             std::memcpy(&out.order[(size_t)at], o.order.data(), o.order.size() * sizeof(int64_t));
-                        at += (int64_t)o.order.size();
+                        at += o.n_order;
                     };
                     append(co[(size_t)c]);
                     for (const CellOut& o : extra[(size_t)c]) append(o);

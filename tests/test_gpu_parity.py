@@ -422,6 +422,29 @@ def test_device_packer_runs_and_solo(mf, k, W):
     assert _same_schedule(mf, U, I, k, uu, ii, rr, blocks=B, waves=W)
 
 
+def test_device_packer_mixed_mode_chunked_cells(mf, oracle):
+    """Rating sets in which SOME cells have to be chunked (too large for the training kernel's LDS image as
+    one chunk): the device keeps the cells that fit, the host packs and chunks the rest, its pieces are
+    scattered into the device arrays -- and the result is still the host packer's bytes."""
+    from mfsgd_amd import _lib
+    from tests.dsgd_common import fuzz_chunked_cases
+
+    n_mixed = 0
+    for c in fuzz_chunked_cases(12, seed=515, max_ratings=9000):
+        packed = _same_schedule(mf, c["U"], c["I"], c["k"], c["u"], c["i"], c["r"], blocks=c["blocks"], waves=c["waves"])
+        with mf.MatrixFactorizationSGD(c["U"], c["I"], c["k"], LR, LAM, 5, blocks=c["blocks"], waves=c["waves"],
+                                       flags=_lib.FLAG_DEVICE_INGEST) as m:
+            m.set_ratings(c["u"], c["i"], c["r"])
+            split = m.schedule_info()["split_cells"]
+        n_mixed += bool(packed and split > 0)
+    assert n_mixed >= 3, n_mixed
+    # a skewed k = 128 set at auto geometry: hot cells chunked, the rest on the device; trained bit-exactly
+    w = mf.synth.workload("cfg3_netflix", 0.05)
+    assert _same_schedule(mf, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"])
+    _, info = _run(mf, oracle, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"], epochs=1)
+    assert info["device_ingest"] == 2
+
+
 def test_device_packer_partitioned_handles(mf):
     """n_parts > 1: every partition's schedule through the device packer (the caller-visible rating
     indices go through the `orig` map)."""
