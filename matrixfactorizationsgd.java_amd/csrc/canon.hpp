@@ -45,8 +45,16 @@ __device__ __forceinline__ float group_allreduce(float v) {
     if constexpr (L >= 4) v = v + dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]   : xor 2
     if constexpr (L >= 8) v = v + dpp_move<0x141>(v);  // row_half_mirror       : other quad
     if constexpr (L >= 16) v = v + dpp_move<0x140>(v); // row_mirror            : other half-row
-    if constexpr (L >= 32) v = swap_add16(v);
-    if constexpr (L >= 64) v = swap_add32(v);
+    if constexpr (L == 32) v = swap_add16(v);
+    if constexpr (L >= 64) {
+        // One rating per wave: the sum is wave-uniform, so the two upper levels need no all-reduce.  Every
+        // lane of row r holds S_r; row_bcast:15 (rows 1, 3) leaves S0+S1 and S2+S3 there, row_bcast:31
+        // (rows 2, 3) leaves (S2+S3)+(S0+S1) in lane 63 -- the bits of the tree above, addition being
+        // commutative -- and a readlane hands it to everybody.  (Rows the masks exclude add 0.)
+        v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+        v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+        v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    }
     return v;
 }
 

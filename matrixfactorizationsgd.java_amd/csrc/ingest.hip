@@ -268,9 +268,11 @@ int pack_count_cb(void* vctx, const PackRequest& q, std::vector<PackCellInfo>& i
     a.u_words = (mu + 31) / 32 + 1;
     a.i_words = (mi + 31) / 32 + 1;
     // rows a cell can touch: at most 2 per rating and at most what the blocks hold; the training kernel's LDS
-    // image (160 KiB) cannot hold more than 10240 16-byte units of rows anyway
-    a.max_rows = (int)std::min<int64_t>(std::min<int64_t>(2 * (int64_t)a.max_m, (int64_t)mu + mi), 32767 / std::max(1, q.L));
-    a.max_rows = std::max(a.max_rows, 8);
+    // image (160 KiB) cannot hold more than 10240 16-byte units of rows anyway.  Most cells touch far fewer, and
+    // the kernel's occupancy hangs on this number (its per-wave state arrays), so a first launch provides for
+    // 512 and only a set with fuller cells pays for a second launch with the full bound.
+    const int rows_full = std::max(8, (int)std::min<int64_t>(std::min<int64_t>(2 * (int64_t)a.max_m, (int64_t)mu + mi), 32767 / std::max(1, q.L)));
+    a.max_rows = std::min(rows_full, 512);
     a.B = q.B;
     a.W = q.W;
     a.G = q.G;
@@ -278,7 +280,11 @@ int pack_count_cb(void* vctx, const PackRequest& q, std::vector<PackCellInfo>& i
     a.lr = q.lr;
     a.c = q.c;
     a.solo_ok = q.solo_ok ? 1 : 0;
-    if (pack_lds_bytes(a) > 160 * 1024 - 256) return 1;
+    {
+        PackArgs worst = a;
+        worst.max_rows = rows_full;
+        if (pack_lds_bytes(worst) > 160 * 1024 - 256) return 1;
+    }
     int rc = -1;
     ING_CHK(hipMalloc(&c->d_r, sizeof(float) * (size_t)std::max<int64_t>(q.n, 1)));
     ING_CHK(hipMemcpy(c->d_r, q.r, sizeof(float) * (size_t)q.n, hipMemcpyHostToDevice));
@@ -303,10 +309,16 @@ int pack_count_cb(void* vctx, const PackRequest& q, std::vector<PackCellInfo>& i
     a.info = c->d_info;
     a.subs = c->d_subs;
     a.emit = 0;
-    ING_CHK(launch_pack(a, n_cells, (hipStream_t)0));
     info.resize((size_t)n_cells);
     subs.resize((size_t)(n_cells * WW));
-    ING_CHK(hipMemcpy(info.data(), c->d_info, sizeof(PackCellInfo) * (size_t)n_cells, hipMemcpyDeviceToHost));
+    for (;;) {
+        ING_CHK(launch_pack(a, n_cells, (hipStream_t)0));
+        ING_CHK(hipMemcpy(info.data(), c->d_info, sizeof(PackCellInfo) * (size_t)n_cells, hipMemcpyDeviceToHost));
+        bool more_rows = false;
+        for (const PackCellInfo& ci : info) more_rows = more_rows || ci.status == 2;
+        if (!more_rows || a.max_rows >= rows_full) break;
+        a.max_rows = rows_full;
+    }
     ING_CHK(hipMemcpy(subs.data(), c->d_subs, sizeof(SubDesc) * (size_t)(n_cells * WW), hipMemcpyDeviceToHost));
     c->args = a;
     c->n_cells = n_cells;

@@ -168,7 +168,9 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
     bool bad = nrows > R || (long long)(nrows + 2 * G) * L > 32767 || nu > 0xFFFF || ni > 0xFFFF;
     if (bad) {
         if (!a.emit && tid == 0) {
-            info.status = 1;
+            info.status = nrows > R ? 2 : 1;  // 2: more rows than this launch's LDS arrays hold (a retry with more may do)
+            info.nu = (unsigned)nu;
+            info.ni = (unsigned)ni;
             a.info[cell] = info;
         }
         return;

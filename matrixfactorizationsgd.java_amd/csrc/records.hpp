@@ -46,7 +46,8 @@ static_assert(sizeof(Entry) == 16, "Entry layout");
 
 // What the device packer (pack.hip) reports per cell after its COUNT pass.
 struct PackCellInfo {
-    uint32_t status;   // 0 ok; 1: the cell does not fit the kernel's arrays / counters (host packer needed)
+    uint32_t status;   // 0 ok; 1: the cell does not fit the kernel's arrays / counters (host packer needed); 2: it has
+                       // more rows than the launch provided for (the device retries with more before giving up)
     uint32_t nu, ni;   // distinct users / items
     uint32_t n_steps;  // step units incl. the two trailing idle steps (0 for an empty cell)
     uint32_t has_run;
