@@ -1,23 +1,42 @@
 """One-off stress beyond the test suite: 400 small random problems and 80 chunk-heavy ones, two
-epochs each on the GPU, factors compared bit for bit with the oracle replaying the exported order.
+epochs each on the GPU, factors compared bit for bit with the oracle replaying the exported order --
+once with the schedule built on the host, once with degrees, bucket order and step packing on the
+device (round 2: pack.hip, mixed mode for the chunk-heavy ones), whose canonical order must also be
+the host's.
 
     python tests/gpu_fuzz_extra.py         # prints "done, mismatches: 0"
 
 Uses the oracle, so it lives under tests/ (not collected by pytest; run it by hand on a GPU box)."""
 import sys, numpy as np
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mfsgd_amd as mf
 from tests.oracle_bind import Oracle
+from mfsgd_amd import _lib
 from tests.dsgd_common import fuzz_cases, fuzz_chunked_cases
 orc = Oracle()
 bad = 0
+n_dev = 0
 def check(c, tag, n):
-    global bad
+    global bad, n_dev
     u, i, r = c["u"], c["i"], c["r"]
-    with mf.MatrixFactorizationSGD(c["U"], c["I"], c["k"], c["lr"], c["lam"], 5, blocks=c["blocks"], waves=c["waves"]) as m:
+    try:
+        with mf.MatrixFactorizationSGD(c["U"], c["I"], c["k"], c["lr"], c["lam"], 5, blocks=c["blocks"], waves=c["waves"],
+                                       flags=_lib.FLAG_HOST_INGEST) as m:
+            m.set_ratings(u, i, r)
+            host_order = m.order()[0]
+    except mf.MfsgdError as e:
+        assert e.code == -7, e  # an explicit B too small for the LDS image: a legal refusal
+        return
+    with mf.MatrixFactorizationSGD(c["U"], c["I"], c["k"], c["lr"], c["lam"], 5, blocks=c["blocks"], waves=c["waves"],
+                                   flags=_lib.FLAG_DEVICE_INGEST) as m:
         m.train(u, i, r, 2, rmse=False)
         P, Q = m.get_factors()
         order, _ = m.order()
+        n_dev += m.schedule_info()["device_ingest"] == 2
+    if not np.array_equal(order, host_order):
+        bad += 1
+        print("ORDER MISMATCH", tag, n, c["U"], c["I"], c["k"], len(u), c["blocks"], c["waves"], flush=True)
     Po, Qo = orc.init_factors(c["U"], c["I"], c["k"], 5)
     for _ in range(2):
         orc.sgd_pass_ordered(Po, Qo, u, i, r, order, c["lr"], c["lam"])
@@ -28,4 +47,4 @@ for n, c in enumerate(fuzz_cases(400, seed=31337)):
     check(c, "small", n)
 for n, c in enumerate(fuzz_chunked_cases(80, seed=777, max_ratings=20000)):
     check(c, "chunked", n)
-print("done, mismatches:", bad)
+print("done, mismatches:", bad, "| schedules the device packed (pure or mixed):", n_dev)
