@@ -223,6 +223,16 @@ int fetch_sorted_cb(void* vctx, int64_t* sorted) {
     return 0;
 }
 
+int fetch_sorted32_cb(void* vctx, uint32_t* sorted) {
+    Ctx* c = static_cast<Ctx*>(vctx);
+    if (!c->d_sorted) return -1;
+    if (c->n > 0 && hipMemcpy(sorted, c->d_sorted, 4 * (size_t)c->n, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return 0;
+}
+
 int bucket_dev_cb(void* vctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
                   int32_t U, int32_t I, int B, int W, int64_t* bptr) {
     Ctx* c = static_cast<Ctx*>(vctx);
@@ -415,7 +425,7 @@ int download_cb(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* en
     return 0;
 }
 
-const DeviceIngestExt kExt = {bucket_dev_cb, fetch_sorted_cb, pack_count_cb, pack_emit_cb, pack_emit_mixed_cb, download_cb};
+const DeviceIngestExt kExt = {bucket_dev_cb, fetch_sorted_cb, fetch_sorted32_cb, pack_count_cb, pack_emit_cb, pack_emit_mixed_cb, download_cb};
 
 }  // namespace
 

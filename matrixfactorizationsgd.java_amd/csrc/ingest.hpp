@@ -67,6 +67,7 @@ struct DeviceIngestExt {
                       int32_t U, int32_t I, int B, int W, int64_t* bptr) = nullptr;
     // the sorted indices after bucket_dev, for the host packer (fallback)
     int (*fetch_sorted)(void* ctx, int64_t* sorted) = nullptr;
+    int (*fetch_sorted32)(void* ctx, uint32_t* sorted) = nullptr;  // the same, as the 32-bit indices the device holds
     // COUNT pass: 0 = done (info: B*B, subs: B*B*W*W), 1 = this rating set is outside what the kernel
     // handles (nothing produced), -1 = a HIP call failed
     int (*pack_count)(void* ctx, const PackRequest& req, std::vector<PackCellInfo>& info, std::vector<SubDesc>& subs) = nullptr;

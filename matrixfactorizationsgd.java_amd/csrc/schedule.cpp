@@ -432,6 +432,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         return (((int64_t)ub * B + it) * W + s) * W + us;
     };
     std::vector<int64_t> sorted;
+    std::vector<uint32_t> sorted32;  // the same thing when it was fetched from the device packer's context
     const DeviceIngestExt* ext = (on_device && prm.device_pack && prm.ingest->ext && prm.ingest->ext->bucket_dev &&
                                   prm.ingest->ext->pack_count && prm.ingest->ext->pack_emit && n > 0)
                                      ? prm.ingest->ext
@@ -598,9 +599,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
             return 0;
         }
-        // the host packer needs the bucket order on this side
-        sorted.resize((size_t)n);
-        if (!ext->fetch_sorted || ext->fetch_sorted(prm.ingest->ctx, sorted.data()) != 0) {
+        // the host packer needs the bucket order on this side (32-bit, as the device holds it)
+        sorted32.resize((size_t)n);
+        if (!ext->fetch_sorted32 || ext->fetch_sorted32(prm.ingest->ctx, sorted32.data()) != 0) {
             err = "build_schedule: could not fetch the bucket order from the device";
             return -1;
         }
@@ -766,7 +767,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         int sb = 0;
         for (int64_t x = lo; x < hi; ++x) {
             while (bptr[(size_t)(c * WW + sb + 1)] <= x) ++sb;
-            const int64_t j = sorted[(size_t)x];
+            const int64_t j = sorted32.empty() ? sorted[(size_t)x] : (int64_t)sorted32[(size_t)x];
             sel[(size_t)(x - lo)] = RawRat{(uint32_t)u[j], (uint32_t)i[j], r[j], orig ? orig[j] : j, (uint16_t)sb};
         }
     };
@@ -865,30 +866,53 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         } else {
             const int64_t s_hi = std::min(max_s, (avail - min_rows) / 2);
             constexpr int kCand = 48;
-            double best_cost = -1;
-            for (int x = 0; x <= kCand; ++x) {
-                int64_t S = min_sched + (s_hi - min_sched) * x / kCand;
-                S = (S + 15) & ~(int64_t)15;
-                if (S > (avail - min_rows) / 2) S = ((avail - min_rows) / 2) & ~(int64_t)15;
-                const int64_t R = (avail - 2 * S) & ~(int64_t)15;
-                double cost = 0;
-                for (int64_t c = 0; c < ncell; ++c) {
-                    const CellOut& o = co[(size_t)c];
-                    if (o.nu + o.ni == 0) continue;
-                    const int64_t rb = rows_bytes_for(geo, (int)(o.nu + o.ni));
-                    // an unpacked (oversize) cell: guess its steps from its rating count
-                    const int64_t sb = oversize[(size_t)c]
-                                           ? sched_bytes_for(geo, W, (int)(o.nu + o.ni), o.n_order * 2 / G + 2)
-                                           : sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps);
-                    if (sb <= S && rb <= R && !oversize[(size_t)c]) continue;
-                    cost += std::max(1.0, std::max((double)sb / (double)S, (double)rb / (double)R));
-                }
-                if (best_cost < 0 || cost < best_cost) {
-                    best_cost = cost;
-                    lim_s = S;
-                    lim_r = R;
-                }
+            // per cell, once: the bytes it needs (an unpacked -- oversize -- cell: steps guessed from its rating count)
+            std::vector<int64_t> need_s((size_t)ncell, 0), need_r((size_t)ncell, 0);
+            for (int64_t c = 0; c < ncell; ++c) {
+                const CellOut& o = co[(size_t)c];
+                if (o.nu + o.ni == 0) continue;
+                need_r[(size_t)c] = rows_bytes_for(geo, (int)(o.nu + o.ni));
+                need_s[(size_t)c] = oversize[(size_t)c] ? sched_bytes_for(geo, W, (int)(o.nu + o.ni), o.n_order * 2 / G + 2)
+                                                        : sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps);
             }
+            // the candidates are independent: one thread each, the winner (lowest cost, then lowest index) as before
+            std::vector<double> cand_cost((size_t)kCand + 1, 0.0);
+            std::vector<int64_t> cand_s((size_t)kCand + 1, 0), cand_r((size_t)kCand + 1, 0);
+            std::atomic<int> next_cand{0};
+            auto eval = [&]() {
+                for (;;) {
+                    const int x = next_cand.fetch_add(1);
+                    if (x > kCand) break;
+                    int64_t S = min_sched + (s_hi - min_sched) * x / kCand;
+                    S = (S + 15) & ~(int64_t)15;
+                    if (S > (avail - min_rows) / 2) S = ((avail - min_rows) / 2) & ~(int64_t)15;
+                    const int64_t R = (avail - 2 * S) & ~(int64_t)15;
+                    double cost = 0;
+                    for (int64_t c = 0; c < ncell; ++c) {
+                        const int64_t rb = need_r[(size_t)c];
+                        if (rb == 0) continue;
+                        const int64_t sb = need_s[(size_t)c];
+                        if (sb <= S && rb <= R && !oversize[(size_t)c]) continue;
+                        cost += std::max(1.0, std::max((double)sb / (double)S, (double)rb / (double)R));
+                    }
+                    cand_cost[(size_t)x] = cost;
+                    cand_s[(size_t)x] = S;
+                    cand_r[(size_t)x] = R;
+                }
+            };
+            {
+                std::vector<std::thread> th;
+                for (int t = 1; t < std::min(nthreads, kCand + 1); ++t) th.emplace_back(eval);
+                eval();
+                for (auto& t : th) t.join();
+            }
+            double best_cost = -1;
+            for (int x = 0; x <= kCand; ++x)
+                if (best_cost < 0 || cand_cost[(size_t)x] < best_cost) {
+                    best_cost = cand_cost[(size_t)x];
+                    lim_s = cand_s[(size_t)x];
+                    lim_r = cand_r[(size_t)x];
+                }
         }
     }
     lap("  chunk limits");
