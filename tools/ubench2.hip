@@ -1,3 +1,8 @@
+// SUPERSEDED by ubench3.hip (round 2), which times the product's own loop texts (csrc/run_asm.hpp).  The
+// body below is NOT the product's run loop: it copies the prefetched p row with four v_mov instead of
+// alternating register sets, which is why it reads 184 cycles per step where the product loop takes 146.
+// Kept for its knock-out variants (what a group of instructions costs), which are ratios, not absolutes.
+//
 // Microbenchmark of the hand-scheduled run step (one wave alone on its SIMD): cycles per
 // step for the full body (V=0) and with groups of instructions knocked out (timing only).
 #include <hip/hip_runtime.h>
