@@ -1,10 +1,11 @@
 """Diagnostic: two independent handles on the same ratings must give bit-identical factors.
-    python tools/determinism.py [SCALE] [FLAGS ...]"""
+    python tools/determinism.py [SCALE] [FLAGS ...]          (workload: MFSGD_WORKLOAD, default cfg2_ml20m)"""
+import os
 import sys
 import numpy as np
 sys.path.insert(0, '.')
 import mfsgd_amd as mf
-w = mf.synth.workload("cfg2_ml20m", float(sys.argv[1]) if len(sys.argv) > 1 else 1.0)
+w = mf.synth.workload(os.environ.get("MFSGD_WORKLOAD", "cfg2_ml20m"), float(sys.argv[1]) if len(sys.argv) > 1 else 1.0)
 for flags in [int(x) for x in sys.argv[2:]] or [0]:
     facs = []
     for rep in range(3):
