@@ -285,7 +285,10 @@ int probe_persistent(mfsgd_handle* h, Part& p) {
         (void)hipGetLastError();
         return MFSGD_OK;  // fall back to one launch per round
     }
-    long np = (long)per_cu * h->n_cu;
+    // DSGD partitions share the GPU with RCCL's send / recv kernels (a few workgroups, on their own stream): leave
+    // them some CUs, or a persistent launch that needs the whole chip would sit in its residency check until the
+    // exchange in flight has finished
+    long np = (long)per_cu * (h->n_parts > 1 ? std::max(1, h->n_cu - 8) : h->n_cu);
     // test hook: pretend the chip holds this many times more workgroups than it does, so that the
     // residency check of the epoch kernel has to fail (tests/test_gpu_parity.py)
     if (const char* f = std::getenv("MFSGD_TEST_OVERSUBSCRIBE")) np *= std::max(1, std::atoi(f));
