@@ -171,3 +171,22 @@ def test_jni_shim_is_well_formed_cpp():
     declared = set(re.findall(r"private static native \S+ (native\w+)\(", java))
     defined = set(re.findall(r"Java_MatrixFactorizationSGD_(native\w+)\(", src))
     assert declared == defined and len(declared) >= 10
+
+
+def test_dsgd_driver_fails_cleanly_without_a_gpu(mf):
+    """The ring under the C-ABI needs a device (and RCCL): on a box without one every entry point returns an
+    error code and a message -- no crash, no hang, nothing half-created."""
+    if have_gpu():
+        pytest.skip("covered on the GPU by tests/test_gpu_parity.py::test_native_dsgd_*")
+    from mfsgd_amd.dsgd import NativeDSGD
+
+    with mf.MatrixFactorizationSGD(10, 9, 8, 0.01, 0.05, 1, n_parts=2) as t:
+        t.set_ratings([0, 1, 2], [0, 1, 2], [1.0, 2.0, 3.0])  # host-side: works without a GPU
+        try:
+            uid = NativeDSGD.unique_id()
+        except mf.MfsgdError as e:
+            assert e.code in (-6, -3, -2), e  # UNSUPPORTED (no librccl), HIP or NO_DEVICE
+            return
+        with pytest.raises(mf.MfsgdError) as ei:
+            NativeDSGD(t, 0, 1, uid)
+        assert ei.value.code in (-2, -3, -4), ei.value
