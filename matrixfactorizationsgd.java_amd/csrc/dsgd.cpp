@@ -16,16 +16,22 @@
 // waits for slot j's arrival only.  With one partition per rank that is train -> shift -> train with
 // no host involvement; with m > 1 the shifts hide behind the training of the other blocks.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mfsgd.h"
@@ -83,6 +89,47 @@ Rccl& rccl() {
 
 thread_local std::string g_dsgd_error;
 
+// ---- the rehearsal transport: blocks staged through POSIX shared memory ------------------------------
+// RCCL cannot put two ranks on one GPU, and a host without RCCL has no ring at all.  With
+// MFSGD_DSGD_TRANSPORT=shm mfsgd_dsgd_unique_id() hands out the name of a shared-memory segment instead of
+// an RCCL id, and a ring created from such an id moves its blocks device -> segment -> device with blocking
+// copies and sequence counters.  Same ring, same order of events, no xGMI: it exists so that the multi-rank
+// logic of this file (groups, slots, double buffering, event ordering, the RMSE reduction) runs -- and is
+// tested -- with several REAL processes on one GPU.  Not a performance path.
+constexpr char kShmMagic[8] = {'M', 'F', 'S', 'G', 'D', 'S', 'H', 'M'};
+constexpr int kShmMaxWorld = 16, kShmMaxSlots = 64;
+struct ShmHeader {
+    std::atomic<uint32_t> ready[kShmMaxWorld];
+    std::atomic<uint64_t> written[kShmMaxWorld][kShmMaxSlots];  // channel (rank -> rank - 1, slot): blocks written
+    std::atomic<uint64_t> taken[kShmMaxWorld][kShmMaxSlots];    // ... and taken by the receiver
+    std::atomic<uint64_t> ar_seq[kShmMaxWorld], ar_done[kShmMaxWorld];
+    double ar_val[kShmMaxWorld][2];
+};
+constexpr size_t kShmDataOffset = (sizeof(ShmHeader) + 4095) & ~(size_t)4095;
+
+struct ShmRing {
+    std::string name;
+    int fd = -1;
+    unsigned char* base = nullptr;
+    size_t bytes = 0, slot_bytes = 0;
+    int rank = 0, world = 1, m = 1;
+    uint64_t ar_round = 0;
+    ShmHeader* hdr() const { return reinterpret_cast<ShmHeader*>(base); }
+    unsigned char* slot(int r, int j) const { return base + kShmDataOffset + ((size_t)r * m + j) * slot_bytes; }
+};
+
+template <class Pred>
+bool spin_until(Pred ok, double seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned n = 0; !ok(); ++n) {
+        if ((n & 1023u) == 1023u) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+            std::this_thread::yield();
+        }
+    }
+    return true;
+}
+
 }  // namespace
 
 struct mfsgd_dsgd {
@@ -92,6 +139,7 @@ struct mfsgd_dsgd {
     int32_t max_rows = 0;
     int64_t nnz_local = 0;
     ncclComm_t comm = nullptr;
+    ShmRing* shm = nullptr;  // the rehearsal transport instead of RCCL (MFSGD_DSGD_TRANSPORT=shm)
     hipStream_t compute = nullptr, wire = nullptr;
     float* buf[2] = {nullptr, nullptr};  // [cur, nxt]: m blocks of max_rows x kp floats each
     int cur = 0;
@@ -133,8 +181,29 @@ int dfail(mfsgd_dsgd* d, int code, const std::string& msg) {
 
 // One ring shift of slot j: the block goes to rank - 1, the next one arrives from rank + 1.
 int shift_slot(mfsgd_dsgd* d, int j, bool after_training) {
-    Rccl& R = rccl();
     const size_t count = (size_t)d->max_rows * d->kp;
+    if (d->shm) {
+        // rehearsal transport: the same shift with blocking copies through shared memory
+        ShmRing& r = *d->shm;
+        ShmHeader* H = r.hdr();
+        const int src = (d->rank + 1) % d->world;
+        if (after_training) DHIP(d, hipEventSynchronize(d->trained[(size_t)j]));
+        auto& wr = H->written[d->rank][j];
+        auto& tk = H->taken[d->rank][j];
+        if (!spin_until([&] { return tk.load(std::memory_order_acquire) == wr.load(std::memory_order_relaxed); }, 120.0))
+            return dfail(d, MFSGD_ERR_HIP, "dsgd (shm transport): rank " + std::to_string((d->rank + d->world - 1) % d->world) + " never took the last block");
+        DHIP(d, hipMemcpy(r.slot(d->rank, j), d->block(d->cur, j), count * sizeof(float), hipMemcpyDeviceToHost));
+        wr.store(wr.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+        auto& swr = H->written[src][j];
+        auto& stk = H->taken[src][j];
+        if (!spin_until([&] { return swr.load(std::memory_order_acquire) > stk.load(std::memory_order_relaxed); }, 120.0))
+            return dfail(d, MFSGD_ERR_HIP, "dsgd (shm transport): rank " + std::to_string(src) + " never sent its block");
+        DHIP(d, hipMemcpy(d->block(d->cur ^ 1, j), r.slot(src, j), count * sizeof(float), hipMemcpyHostToDevice));
+        stk.store(stk.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+        DHIP(d, hipEventRecord(d->arrived[(size_t)j], d->wire));
+        return MFSGD_OK;
+    }
+    Rccl& R = rccl();
     if (after_training) DHIP(d, hipStreamWaitEvent(d->wire, d->trained[(size_t)j], 0));
     DNCCL(d, R.GroupStart());
     DNCCL(d, R.Send(d->block(d->cur, j), count, ncclFloat, (d->rank + d->world - 1) % d->world, d->comm, d->wire));
@@ -194,6 +263,36 @@ int local_sse(mfsgd_dsgd* d, double* out) {
 }
 
 int allreduce2(mfsgd_dsgd* d, double* v, ncclRedOp_t op) {
+    if (d->shm) {
+        ShmRing& r = *d->shm;
+        ShmHeader* H = r.hdr();
+        const uint64_t q = ++r.ar_round;
+        // nobody may still be reading the previous round's values
+        if (!spin_until([&] {
+                for (int x = 0; x < d->world; ++x)
+                    if (H->ar_done[x].load(std::memory_order_acquire) + 1 < q) return false;
+                return true;
+            }, 120.0))
+            return dfail(d, MFSGD_ERR_HIP, "dsgd (shm transport): all-reduce, a rank is missing");
+        H->ar_val[d->rank][0] = v[0];
+        H->ar_val[d->rank][1] = v[1];
+        H->ar_seq[d->rank].store(q, std::memory_order_release);
+        if (!spin_until([&] {
+                for (int x = 0; x < d->world; ++x)
+                    if (H->ar_seq[x].load(std::memory_order_acquire) < q) return false;
+                return true;
+            }, 120.0))
+            return dfail(d, MFSGD_ERR_HIP, "dsgd (shm transport): all-reduce, a rank is missing");
+        double a = H->ar_val[0][0], b = H->ar_val[0][1];
+        for (int x = 1; x < d->world; ++x) {  // rank order: every rank gets the same bits
+            a = op == ncclSum ? a + H->ar_val[x][0] : std::max(a, H->ar_val[x][0]);
+            b = op == ncclSum ? b + H->ar_val[x][1] : std::max(b, H->ar_val[x][1]);
+        }
+        v[0] = a;
+        v[1] = b;
+        H->ar_done[d->rank].store(q, std::memory_order_release);
+        return MFSGD_OK;
+    }
     DHIP(d, hipMemcpyAsync(d->d_red, v, 2 * sizeof(double), hipMemcpyHostToDevice, d->wire));
     DNCCL(d, rccl().AllReduce(d->d_red, d->d_red, 2, ncclDouble, op, d->comm, d->wire));
     DHIP(d, hipMemcpyAsync(v, d->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, d->wire));
@@ -210,6 +309,15 @@ const char* mfsgd_dsgd_last_error(const mfsgd_dsgd* d) { return d ? d->err.c_str
 int mfsgd_dsgd_unique_id(void* id_out) {
     if (!id_out) return dfail(nullptr, MFSGD_ERR_INVALID_ARG, "dsgd_unique_id: null argument");
     static_assert(sizeof(ncclUniqueId) <= MFSGD_DSGD_ID_BYTES, "id buffer");
+    if (const char* tr = std::getenv("MFSGD_DSGD_TRANSPORT"))
+        if (std::strcmp(tr, "shm") == 0) {
+            // the rehearsal transport: the id is the name of a shared-memory segment
+            std::memset(id_out, 0, MFSGD_DSGD_ID_BYTES);
+            std::memcpy(id_out, kShmMagic, sizeof kShmMagic);
+            const auto now = std::chrono::steady_clock::now().time_since_epoch().count();
+            std::snprintf(static_cast<char*>(id_out) + 8, MFSGD_DSGD_ID_BYTES - 8, "/mfsgd_%d_%llx", (int)getpid(), (unsigned long long)now);
+            return MFSGD_OK;
+        }
     Rccl& R = rccl();
     if (!R.lib) return dfail(nullptr, MFSGD_ERR_UNSUPPORTED, "RCCL is not available: " + R.why);
     ncclUniqueId id;
@@ -224,8 +332,10 @@ int mfsgd_dsgd_create(mfsgd_handle* h, int32_t rank, int32_t world, const void* 
     if (out) *out = nullptr;
     if (!h || !id || !out || world < 1 || rank < 0 || rank >= world)
         return dfail(nullptr, MFSGD_ERR_INVALID_ARG, "dsgd_create: bad argument");
+    const bool use_shm = std::memcmp(id, kShmMagic, sizeof kShmMagic) == 0;
     Rccl& R = rccl();
-    if (!R.lib) return dfail(nullptr, MFSGD_ERR_UNSUPPORTED, "RCCL is not available: " + R.why);
+    if (!use_shm && !R.lib) return dfail(nullptr, MFSGD_ERR_UNSUPPORTED, "RCCL is not available: " + R.why);
+    if (use_shm && world > kShmMaxWorld) return dfail(nullptr, MFSGD_ERR_UNSUPPORTED, "dsgd (shm transport): at most 16 ranks");
     int32_t n_parts = 0, kp = 0, device = 0, k = 0;
     if (mfsgd_get_parts(h, &n_parts, &kp, &device) != MFSGD_OK || mfsgd_get_dims(h, nullptr, nullptr, &k) != MFSGD_OK)
         return dfail(nullptr, MFSGD_ERR_INVALID_ARG, "dsgd_create: bad handle");
@@ -283,6 +393,44 @@ int mfsgd_dsgd_create(mfsgd_handle* h, int32_t rank, int32_t world, const void* 
         if (hip(hipEventCreateWithFlags(&d->trained[(size_t)j], hipEventDisableTiming), "hipEventCreate") ||
             hip(hipEventCreateWithFlags(&d->arrived[(size_t)j], hipEventDisableTiming), "hipEventCreate"))
             return bail(MFSGD_ERR_HIP);
+    if (use_shm) {
+        if (d->m > kShmMaxSlots) {
+            d->err = "dsgd_create (shm transport): at most 64 partitions per rank";
+            return bail(MFSGD_ERR_UNSUPPORTED);
+        }
+        ShmRing* sr = new (std::nothrow) ShmRing();
+        if (!sr) return bail(MFSGD_ERR_OOM);
+        d->shm = sr;
+        sr->name.assign(static_cast<const char*>(id) + 8, strnlen(static_cast<const char*>(id) + 8, MFSGD_DSGD_ID_BYTES - 9));
+        sr->rank = rank;
+        sr->world = world;
+        sr->m = d->m;
+        sr->slot_bytes = (size_t)d->max_rows * kp * sizeof(float);
+        sr->bytes = kShmDataOffset + (size_t)world * d->m * sr->slot_bytes;
+        sr->fd = shm_open(sr->name.c_str(), O_CREAT | O_RDWR, 0600);
+        if (sr->fd < 0 || ftruncate(sr->fd, (off_t)sr->bytes) != 0) {
+            d->err = "dsgd_create (shm transport): cannot create " + sr->name;
+            return bail(MFSGD_ERR_OOM);
+        }
+        void* mp = mmap(nullptr, sr->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, sr->fd, 0);
+        if (mp == MAP_FAILED) {
+            d->err = "dsgd_create (shm transport): cannot map " + sr->name;
+            return bail(MFSGD_ERR_OOM);
+        }
+        sr->base = static_cast<unsigned char*>(mp);  // a fresh segment is all zeros: every counter starts at 0
+        ShmHeader* H = sr->hdr();
+        H->ready[rank].store(1, std::memory_order_release);
+        if (!spin_until([&] {
+                for (int x = 0; x < world; ++x)
+                    if (H->ready[x].load(std::memory_order_acquire) == 0) return false;
+                return true;
+            }, 120.0)) {
+            d->err = "dsgd_create (shm transport): not every rank arrived";
+            return bail(MFSGD_ERR_HIP);
+        }
+        *out = d;
+        return MFSGD_OK;
+    }
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof uid);
     ncclResult_t r = R.CommInitRank(&d->comm, world, uid, rank);
@@ -301,6 +449,12 @@ void mfsgd_dsgd_destroy(mfsgd_dsgd* d) {
     if (d->compute) (void)hipStreamSynchronize(d->compute);
     if (d->wire) (void)hipStreamSynchronize(d->wire);
     if (d->comm) (void)rccl().CommDestroy(d->comm);
+    if (d->shm) {
+        if (d->shm->base) (void)munmap(d->shm->base, d->shm->bytes);
+        if (d->shm->fd >= 0) (void)close(d->shm->fd);
+        if (d->rank == 0 && !d->shm->name.empty()) (void)shm_unlink(d->shm->name.c_str());
+        delete d->shm;
+    }
     for (hipEvent_t e : d->trained)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->arrived)

@@ -89,6 +89,18 @@ def assemble_q_plan(blocks, ip, I, k):
     return Q
 
 
+def native_problem():
+    """The rating set of the multi-process test of the C-ABI DSGD driver: every rank rebuilds it from the seed."""
+    U, I, k, nnz, epochs = 2400, 900, 64, 90000, 2
+    rng = np.random.default_rng(77)
+    wu, wi = 1.0 / (np.arange(U) + 4.0), 1.0 / (np.arange(I) + 2.0)
+    key = np.unique(rng.choice(U, nnz, p=wu / wu.sum()).astype(np.int64) * I + rng.choice(I, nnz, p=wi / wi.sum()))
+    key = rng.permutation(key)
+    u, i = (key // I).astype(np.int32), (key % I).astype(np.int32)
+    r = (rng.random(u.size) * 4 + 1).astype(np.float32)
+    return U, I, k, u, i, r, epochs
+
+
 class OracleBackend:
     """CPU stand-in for dsgd.HipBackend (tests only)."""
 

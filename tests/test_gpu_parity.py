@@ -774,6 +774,73 @@ def test_native_dsgd_world1_self_ring(mf, oracle, m, k):
     assert np.array_equal(P1, Po)
 
 
+@pytest.mark.parametrize("world,m", [(2, 1), (3, 1), (2, 2)])
+def test_native_dsgd_multi_process_shm(mf, oracle, tmp_path, monkeypatch, world, m):
+    """The ring under the C-ABI with SEVERAL REAL PROCESSES (world 2 and 3, one and two partitions per rank):
+    one global rating set cut by mfsgd_dsgd_plan, every rank a process of its own driving csrc/dsgd.cpp, the
+    blocks moved by the driver's shared-memory rehearsal transport (RCCL refuses two ranks on one GPU; with
+    RCCL only ncclSend / ncclRecv / ncclAllReduce differ).  Factors, Q blocks and the RMSE trajectory against
+    the sequential DSGD definition run by the oracle over global factors: bit-exact."""
+    import os
+    import subprocess
+    import sys
+
+    from mfsgd_amd.dsgd import NativeDSGD
+    from tests.conftest import ROOT
+    from tests.dsgd_common import LAM as DL, LR as DLR, SEED, native_problem, plan_shards, plan_trainer
+
+    monkeypatch.setenv("MFSGD_DSGD_TRANSPORT", "shm")
+    uid = NativeDSGD.unique_id()
+    assert uid[:8] == b"MFSGDSHM"
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dsgd_native_worker.py"), str(rk), str(world), str(m),
+                               uid.hex(), str(tmp_path)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for rk in range(world)]
+    outs = []
+    for pr in procs:
+        try:
+            outs.append(pr.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for rk, (pr, o) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0, f"rank {rk}:\n{o[-3000:]}"
+    U, I, k, u, i, r, epochs = native_problem()
+    n_parts = world * m
+    ub, _, sel = plan_shards(mf, U, I, u, i, world)
+    _, ip = mf.dsgd_plan(np.bincount(u, minlength=U), np.bincount(i, minlength=I), n_parts)
+    got = [np.load(tmp_path / f"rank{rk}.npz") for rk in range(world)]
+    P = np.concatenate([g["P"] for g in got])
+    Q = np.zeros((I, k), np.float32)
+    seen = []
+    for g in got:
+        for part in g["parts"]:
+            idx = np.flatnonzero(ip == part)
+            Q[idx] = g[f"q{part}"][: idx.size]
+            seen.append(int(part))
+    assert sorted(seen) == list(range(n_parts))
+    # the sequential definition: sub-epoch s, rank g trains the partitions of group (g + s) % world, one after another
+    trainers = [plan_trainer(mf, g, ub, ip, sel, I, k, u, i, r, n_parts) for g in range(world)]
+    Po, Qo = oracle.init_factors(U, I, k, SEED)
+    rm0 = oracle.rmse(Po, Qo, u, i, r)
+    ref = []
+    for _ in range(epochs):
+        for s in range(world):
+            for g in range(world):
+                for j in range(m):
+                    part = ((g + s) % world) * m + j
+                    oracle.sgd_pass_ordered(Po, Qo, u, i, r, sel[g][trainers[g].order(part)[0]], DLR, DL)
+        ref.append(oracle.rmse(Po, Qo, u, i, r))
+    for t in trainers:
+        t.close()
+    assert np.array_equal(P, Po), "P differs from the sequential DSGD definition"
+    assert np.array_equal(Q, Qo), "Q differs from the sequential DSGD definition"
+    for g in got:
+        assert abs(float(g["rm0"]) - rm0) <= 1e-9
+        np.testing.assert_allclose(g["rm"], ref, rtol=1e-9)
+        assert np.abs(g["rm"] - np.array(ref)).max() <= RMSE_TOL
+
+
 def test_native_dsgd_rejects_bad_arguments(mf):
     from mfsgd_amd.dsgd import NativeDSGD
 
