@@ -289,6 +289,10 @@ int mfsgd_get_parts(const mfsgd_handle* h, int32_t* n_parts, int32_t* kp, int32_
  * a communication stream, ordered against the compute stream with events, no host
  * synchronisation inside an epoch.  RCCL is bound at run time (librccl.so.1, or
  * MFSGD_RCCL_LIBRARY); without it these calls return MFSGD_ERR_UNSUPPORTED.
+ * Rehearsal on one GPU: if MFSGD_DSGD_TRANSPORT=shm is set when mfsgd_dsgd_unique_id runs, the id
+ * names a POSIX shared-memory segment and the ranks (processes of one host) move the blocks
+ * through it instead of RCCL -- same results, host-copy speed, for testing a host's multi-process
+ * logic where RCCL cannot run (two ranks on one GPU).
  * Java: MatrixFactorizationSGD.trainDistributed(...).               */
 typedef struct mfsgd_dsgd mfsgd_dsgd;
 #define MFSGD_DSGD_ID_BYTES 128
