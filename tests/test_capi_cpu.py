@@ -190,3 +190,22 @@ def test_dsgd_driver_fails_cleanly_without_a_gpu(mf):
         with pytest.raises(mf.MfsgdError) as ei:
             NativeDSGD(t, 0, 1, uid)
         assert ei.value.code in (-2, -3, -4), ei.value
+
+
+def test_dsgd_rehearsal_id_names_a_shared_memory_segment(mf, monkeypatch):
+    """MFSGD_DSGD_TRANSPORT=shm: the 128-byte id is the magic and a segment name (no RCCL, no GPU needed for
+    the id); creating the ring still needs a device and fails cleanly here, leaving no segment behind."""
+    from mfsgd_amd.dsgd import NativeDSGD
+
+    monkeypatch.setenv("MFSGD_DSGD_TRANSPORT", "shm")
+    a, b = NativeDSGD.unique_id(), NativeDSGD.unique_id()
+    assert len(a) == 128 and a[:8] == b"MFSGDSHM" and a != b
+    name = a[8:].split(b"\0")[0].decode()
+    assert name.startswith("/mfsgd_")
+    if have_gpu():
+        return
+    with mf.MatrixFactorizationSGD(10, 9, 8, 0.01, 0.05, 1, n_parts=2) as t:
+        t.set_ratings([0, 1, 2], [0, 1, 2], [1.0, 2.0, 3.0])
+        with pytest.raises(mf.MfsgdError):
+            NativeDSGD(t, 0, 1, a)
+    assert not os.path.exists("/dev/shm" + name)
