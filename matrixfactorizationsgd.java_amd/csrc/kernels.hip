@@ -53,6 +53,7 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
     static_assert(L == 16 || L == 32 || L == 64, "hand-scheduled run loop: 16, 32 or 64 lanes per rating");
     using f4 = __attribute__((ext_vector_type(4))) float;
     f4 q = {rq.x, rq.y, rq.z, rq.w};
+    constexpr int PADV = mfsgd_pad_run(L);
     if constexpr (L == 16)
         asm volatile(MFSGD_RUN_LOOP_ASM_TEXT("", MFSGD_SFMA_V) MFSGD_RUN_LOOP_ASM_OPERANDS);
     else if constexpr (L == 32)
@@ -71,6 +72,7 @@ __device__ __forceinline__ void solo_chain_asm(const float4 rq, const unsigned e
     static_assert(L == 16 || L == 32 || L == 64, "solo loops: 16, 32 or 64 lanes per rating");
     using f4 = __attribute__((ext_vector_type(4))) float;
     const f4 q = {rq.x, rq.y, rq.z, rq.w};
+    constexpr int PADV = mfsgd_pad_chain(L);
     if constexpr (L == 16)
         asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT("", MFSGD_SFMA_V) MFSGD_SOLO_CHAIN_OPERANDS);
     else if constexpr (L == 32)
@@ -80,7 +82,9 @@ __device__ __forceinline__ void solo_chain_asm(const float4 rq, const unsigned e
 }
 // Returns false if it gave up waiting for the chain wave (bounded polling; cannot happen with a
 // schedule the packer built -- the bound only keeps a corrupt one from hanging the GPU).
+template <int L>
 __device__ __forceinline__ bool solo_helper_asm(const unsigned ea, const unsigned rowbase, int n, const uint64_t c2) {
+    constexpr int PADV = mfsgd_pad_helper(L);
     int spins = 1 << 22;
     asm volatile(MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_OPERANDS);
     return spins != 0;
@@ -208,7 +212,12 @@ struct Cell {
     // wave instruction moves G whole rows (64 lanes x 16 B = G x ROWB contiguous LDS
     // bytes); the source address is per lane, so it is a row gather.  Issues every
     // load of the wave back to back and does NOT wait: caller does vmcnt(0) + barrier.
+    // COH: the loads carry sc1 (they bypass this CU's L1), for rows another workgroup stored write-through inside
+    // the same launch -- the ring hand-off then needs no acquire fence in front of them (Guideline 16, form R1
+    // with sc1 loads in place of the acquire).
+    template <bool COH = false>
     __device__ __forceinline__ void gather(const float* __restrict__ P, const float* __restrict__ Q, int lo, int hi) {
+        constexpr int AUX = COH ? 16 : 0;  // cache policy bits of the builtin: 16 = sc1
         constexpr int UNR = 4;  // row ids of UNR instructions are fetched before any of them is issued
         const int first = (lo / G) * G;  // keep wave instructions aligned to G-slot groups
         int s0 = first + wave_all * G;
@@ -226,7 +235,7 @@ struct Cell {
                 const int sb = s0 + x * NWV * G;
                 if (in[x]) {
                     const float* src = (sb + g < nu ? P : Q) + (size_t)rid[x] * KP + lig * 4;
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lrows + (size_t)sb * ROWB), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lrows + (size_t)sb * ROWB), 16, 0, AUX);
                 }
             }
         }
@@ -235,7 +244,7 @@ struct Cell {
             if (sx >= lo && sx < hi) {
                 const uint32_t rid = lids[sx];
                 const float* src = (sx < nu ? P : Q) + (size_t)rid * KP + lig * 4;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lrows + (size_t)s0 * ROWB), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lrows + (size_t)s0 * ROWB), 16, 0, AUX);
             }
         }
     }
@@ -301,7 +310,7 @@ struct Cell {
                             const int first = __builtin_amdgcn_readfirstlane((int)((sd.x & 0xFFFFu) + (sd.y & 0xFFFFu) + (sd.y >> 16))) + kSoloPad;
                             const uint4* hdr = lent + (size_t)first * G;
                             const uint64_t c2 = ((uint64_t)__builtin_bit_cast(unsigned, c) << 32) | __builtin_bit_cast(unsigned, c);
-                            if (!solo_helper_asm((unsigned)(uintptr_t)(lptr_t)hdr, (unsigned)(uintptr_t)(lptr_t)lr_ + lo, ns, c2))
+                            if (!solo_helper_asm<L>((unsigned)(uintptr_t)(lptr_t)hdr, (unsigned)(uintptr_t)(lptr_t)lr_ + lo, ns, c2))
                                 if (fail_flag) *fail_flag = 1;
                         }
                     }
@@ -723,8 +732,12 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
                         }
                     }
                 }
+#ifdef MFSGD_ACQUIRE_HANDOFF
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+                asm volatile("" ::: "memory");  // the tile's rows are loaded sc1 below: no acquire (it cost ~1.5 us per round)
+#endif
             }
         }
         mark(1);  // waiting for the tile (wave 0)
@@ -736,7 +749,11 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         }
         (void)0;
         const Item it2 = next_item(it1, cd1);
+#ifdef MFSGD_ACQUIRE_HANDOFF
         if (work) cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
+#else
+        if (work) cx.template gather<true>(P, Q, cx.nu, cx.nrows);  // the tile's q rows, sc1: stored by another CU
+#endif
         // descriptor used two iterations from now: a scalar load issued here, behind every gather of
         // this iteration, so that it completes in the shadow of the wait for the rows
         if (it2.R < n_rounds) cd2 = load_desc(cells, it2.idx);

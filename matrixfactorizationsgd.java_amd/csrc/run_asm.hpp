@@ -20,6 +20,36 @@
 // Shared with tools/ubench3.hip, which times the two loops against each other in isolation.
 #pragma once
 
+// The loops below are a few 64-byte instruction-cache lines long and their cycle count per pass depends on
+// where the loop head sits inside a 32-byte fetch window (tools/ubench3.hip built with -DMFSGD_PAD_*=n;
+// period 8 instructions).  Cycles per step at 0 / 2 / 4 / 6 s_nops past a 64-byte boundary:
+//     solo pair   L = 16: 136.1 137.5 133.7 138.8    L = 32: 165.4 168.6 174.3 178.0    L = 64: 173.4 175.4 170.3 176.4
+//     run loop    L = 16: 145.6 143.6 149.6 151.6    L = 32: 174.5 174.5 182.4 180.4    L = 64: 177.8 177.7 181.7 183.7
+// Every loop head is therefore placed explicitly (operand [pad], an assembly-time constant): the product
+// runs the layout that was timed, whatever code the compiler puts in front of the loop.
+constexpr int mfsgd_pad_run(int lanes) {
+#ifdef MFSGD_PAD_RUN
+    return MFSGD_PAD_RUN;
+#else
+    return 2;
+#endif
+}
+constexpr int mfsgd_pad_chain(int lanes) {
+#ifdef MFSGD_PAD_CHAIN
+    return MFSGD_PAD_CHAIN;
+#else
+    return lanes == 32 ? 0 : 4;
+#endif
+}
+constexpr int mfsgd_pad_helper(int lanes) {
+#ifdef MFSGD_PAD_HELPER
+    return MFSGD_PAD_HELPER;
+#else
+    return lanes == 32 ? 0 : 4;
+#endif
+}
+#define MFSGD_LOOP_ALIGN ".p2align 6\n\t.rept %c[pad]\n\ts_nop 0\n\t.endr\n\t"
+
 // ---- hand-scheduled run loop (gfx950) ---------------------------------------------------
 // `pairs` x 2 run steps of one wave: resident q rows in v[100:103] / v[140:143] (alternating),
 // one p row prefetched a step ahead, entry words fetched one / two steps ahead.  Per step:
@@ -57,6 +87,7 @@
         "v_lshl_add_u32 v112, v133, 4, v139\n\t" \
         "ds_read_b128 v[104:107], v112\n\t" \
         "ds_write_b32 v138, v114\n\t" \
+        MFSGD_LOOP_ALIGN \
         "1:\n\t" \
         "s_waitcnt lgkmcnt(1)\n\t" \
         "v_pk_mul_f32 v[120:121], v[104:105], v[100:101]\n\t" \
@@ -130,7 +161,7 @@
 #define MFSGD_RUN_LOOP_ASM_OPERANDS                                                                                   \
     : [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [n] "+s"(pairs)                              \
     : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [e1] "n"(EST), [e2] "n"(2 * EST), [e3] "n"(3 * EST),              \
-      [e1p8] "n"(EST + 8), [e2p8] "n"(2 * EST + 8)                                                                     \
+      [e1p8] "n"(EST + 8), [e2p8] "n"(2 * EST + 8), [pad] "n"(PADV)                                                                    \
     : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
       "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",  \
       "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139",  \
@@ -184,6 +215,7 @@
         "ds_write_b32 v138, v133 offset:4\n\t" \
         "s_nop 1\n\t" \
         "v_add_u32 v138, 16, v138\n\t" \
+        MFSGD_LOOP_ALIGN \
         "1:\n\t" \
         MFSGD_SOLO_CHAIN_HALF("104", "105", "106", "107", "108", "109", "110", "111", "116", "117", "118:119", "16", "8", EXTRA, SFMA) \
         "s_cbranch_scc1 2f\n\t" \
@@ -196,7 +228,7 @@
 #define MFSGD_SOLO_CHAIN_OPERANDS                                                                                      \
     : [n] "+s"(n)                                                                                                      \
     : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [c2] "s"(c2), [q0] "v"(q[0]), [q1] "v"(q[1]), [q2] "v"(q[2]),     \
-      [q3] "v"(q[3])                                                                                                   \
+      [q3] "v"(q[3]), [pad] "n"(PADV)                                                                                  \
     : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
       "v113", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v130", "v131", "v132",  \
       "v133", "v138", "v139"
@@ -271,6 +303,7 @@
         "ds_write_b32 v138, v133 offset:4\n\t" \
         "s_nop 1\n\t" \
         "v_add_u32 v138, 16, v138\n\t" \
+        MFSGD_LOOP_ALIGN \
         "5:\n\t" \
         MFSGD_SOLO_HELPER_HALF("0", "104", "105", "106", "107", "108", "111", "116", "117", "116:117", "118:119", "112", "113", "offset0:6 offset1:5", "8") \
         "s_cbranch_scc1 8f\n\t" \
@@ -288,7 +321,7 @@
 
 #define MFSGD_SOLO_HELPER_OPERANDS                                                                                     \
     : [n] "+s"(n), [spins] "+s"(spins)                                                                                 \
-    : [ea] "v"(ea), [rb] "v"(rowbase), [c2] "s"(c2)                                                                    \
+    : [ea] "v"(ea), [rb] "v"(rowbase), [c2] "s"(c2), [pad] "n"(PADV)                                                                 \
     : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110",  \
       "v111", "v112", "v113", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",  \
       "v129", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140"

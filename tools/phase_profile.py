@@ -1,7 +1,11 @@
 """Diagnostic: per-phase shader cycles of one persistent epoch (mfsgd_debug_epoch_profile).
 
-    python tools/phase_profile.py WORKLOAD SCALE [BLOCKS [WAVES]]
+    python tools/phase_profile.py WORKLOAD SCALE [BLOCKS [WAVES [FLAGS]]]
+
+MFSGD_EMU=N in the environment: profile ONE partition of the N-rank weak-scaling job of bench.py (N times the
+items, the global plan's partition 0 as a problem of its own).
 """
+import os
 import sys
 import time
 
@@ -14,7 +18,15 @@ name, scale = sys.argv[1], float(sys.argv[2])
 blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 waves = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 flags = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-w = mf.synth.workload(name, scale)
+emu = int(os.environ.get("MFSGD_EMU", "1"))
+w = mf.synth.workload(name, scale, item_mult=emu)
+if emu > 1:
+    _, ip = mf.dsgd_plan(np.ones(1, np.int64), np.bincount(w["i"], minlength=w["I"]), emu)
+    keep = ip[w["i"]] == 0
+    new_id = np.cumsum(ip == 0) - 1
+    w["u"], w["i"], w["r"] = w["u"][keep], new_id[w["i"][keep]].astype(np.int32), w["r"][keep]
+    w["I"] = int((ip == 0).sum())
+    print(f"partition 0 of {emu}: {keep.sum()} ratings, {w['I']} items, heaviest item {np.bincount(w['i']).max()}")
 with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], 0.01, 0.05, 3, blocks=blocks, waves=waves, flags=flags) as m:
     m.set_ratings(w["u"], w["i"], w["r"])
     m.init_factors()

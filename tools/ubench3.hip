@@ -63,14 +63,17 @@ __global__ void __launch_bounds__(128) k(const float* rows_in, const uint32_t* e
         const unsigned ea = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + RUN_OFF) + g * 16;
         int pairs = n_steps / 2;
         constexpr int EST = GS * 16;
+        constexpr int PADV = mfsgd_pad_run(LG);
         asm volatile(MFSGD_RUN_LOOP_ASM_TEXT(EXTRA, SFMA) MFSGD_RUN_LOOP_ASM_OPERANDS);
         if (g == 0) *(f4*)(smem + qaddr) = q;
     } else if (wave == 0 && mode != 2) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 q = *(const f4*)(smem + NSTEP * ROWB + (lane % LG) * 16);
+        constexpr int PADV = mfsgd_pad_chain(LG);
         asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA, SFMA) MFSGD_SOLO_CHAIN_OPERANDS);
     } else if (wave == 1 && (mode == 0 || mode == 2)) {
         int spins = 1 << 20;
+        constexpr int PADV = mfsgd_pad_helper(LG);
         asm volatile(MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_OPERANDS);
         if (spins == 0 && lane == 0) cyc[2] = 1;
     }
