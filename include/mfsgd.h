@@ -202,10 +202,11 @@ int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cell
                              uint32_t* subs, uint32_t* entries);
 
 /* Diagnostic (not part of the Java surface): runs ONE epoch with the persistent kernel and
- * returns, per workgroup, 8 words: shader cycles wave 0 spent in (0) draining its previous
+ * returns, per workgroup, 16 words: shader cycles wave 0 spent in (0) draining its previous
  * stores and issuing prefetch + own-row gather, (1) waiting for the tile, (2) the barrier after
  * it, (3) the tile gather, (4) the ratings, (5) storing + publishing the tile, (6) storing its
- * own rows; word 7 unused.  out must hold blocks x 8 words.  It DOES apply the epoch.           */
+ * own rows; (7) the longest single ratings phase (its slowest cell); (8..14) the seven phases of
+ * the pass that contained it; (15) unused.  out must hold blocks x 16 words.  It DOES apply the epoch. */
 int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgroups);
 
 /* Diagnostic: out4 = {times a persistent launch found its workgroups not co-resident and the library

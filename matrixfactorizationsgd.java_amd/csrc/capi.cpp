@@ -1151,7 +1151,7 @@ int mfsgd_debug_epoch_profile(mfsgd_handle* h, uint64_t* out, int32_t* n_workgro
     Part& p = h->parts[0];
     if ((rc = probe_persistent(h, p))) return rc;
     if (p.persistent_np <= 0) return fail(h, MFSGD_ERR_STATE, "debug_epoch_profile: persistent kernel not in use");
-    const size_t words = (size_t)p.persistent_np * 8;
+    const size_t words = (size_t)p.persistent_np * 16;
     if ((rc = dev_alloc(h, p.d_sse_partial, std::max(words * sizeof(uint64_t), sizeof(double) * p.sched.cells.size())))) return rc;
     CellLaunch a = make_launch(h, p, static_cast<float*>(h->dQ.p));
     a.grid = p.persistent_np;

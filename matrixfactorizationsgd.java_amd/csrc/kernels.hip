@@ -693,12 +693,17 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
 
     // optional phase accounting (diagnostic launches only): shader cycles of wave 0 per phase
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [7]: the longest single "ratings" phase (its slowest cell)
+    unsigned long long pcur[7] = {0, 0, 0, 0, 0, 0, 0}, pmax[7] = {0, 0, 0, 0, 0, 0, 0};  // this pass / the pass of [7]
     unsigned long long pt = 0;
     auto mark = [&](int k) {
         if (prof) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             pacc[k] += now - pt;
-            if (k == 4 && now - pt > pacc[7]) pacc[7] = now - pt;
+            pcur[k] = now - pt;
+            if (k == 6 && pcur[4] > pacc[7]) {  // end of a pass whose ratings phase is the longest so far
+                pacc[7] = pcur[4];
+                for (int x = 0; x < 7; ++x) pmax[x] = pcur[x];
+            }
             pt = now;
         }
     };
@@ -791,8 +796,10 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         __hip_atomic_store((gu32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wg == 0 && cx.tid == 0)  // launches that got past the residency check (the host counts on it when one did not)
         __hip_atomic_fetch_add((gu32*)(abort_word + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prof && cx.tid == 0)
-        for (int k = 0; k < 8; ++k) prof[(size_t)wg * 8 + k] = pacc[k];
+    if (prof && cx.tid == 0) {
+        for (int k = 0; k < 8; ++k) prof[(size_t)wg * 16 + k] = pacc[k];
+        for (int k = 0; k < 7; ++k) prof[(size_t)wg * 16 + 8 + k] = pmax[k];
+    }
 }
 
 template <int L, int W>

@@ -41,18 +41,37 @@ namespace {
 // Longest-processing-time-first assignment of rows to `nbins` bins by rating
 // count.  Rows with no rating go to bin 0 (they are never touched).
 // Deterministic: ties broken by row index / bin index.
-void lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>& bin) {
+// `stride` > 0 (the item side of a schedule: bin f belongs to tile f % stride): a row that fills a bin by
+// itself -- its count is at least the mean bin load, so LPT adds nothing to its bin -- and whose chain of
+// dependent updates is long enough to be what the epoch waits for (count >= giant_min)
+// gets its TILE to itself as well: the tile's other bins stay empty.  With nothing else in its tile, the
+// hand-off of that tile moves one row instead of a hundred and its cell holds no work but the chain.  (The giants are the first rows LPT
+// places, into bins 0, 1, ... in this order, so their tiles are known before anything else is placed.)
+void lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>& bin, int stride = 0,
+                int64_t giant_min = 0) {
     const int64_t n = (int64_t)deg.size();
     bin.assign((size_t)n, 0);
     std::vector<int32_t> idx;
     idx.reserve((size_t)n);
+    int64_t total = 0;
     for (int64_t x = 0; x < n; ++x)
-        if (deg[(size_t)x] > 0) idx.push_back((int32_t)x);
+        if (deg[(size_t)x] > 0) {
+            idx.push_back((int32_t)x);
+            total += deg[(size_t)x];
+        }
     std::stable_sort(idx.begin(), idx.end(),
                      [&](int32_t a, int32_t b) { return deg[(size_t)a] > deg[(size_t)b]; });
+    int giants = 0;
+    if (stride > 0 && stride < nbins) {
+        const int64_t mean = (total + nbins - 1) / nbins;
+        while (giants < (int)idx.size() && giants < stride / 4 &&
+               deg[(size_t)idx[(size_t)giants]] >= std::max(mean, giant_min))
+            ++giants;
+    }
     using Item = std::pair<int64_t, int32_t>;  // (load, bin): smallest load, then smallest bin
     std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
-    for (int32_t b = 0; b < nbins; ++b) heap.push({0, b});
+    for (int32_t b = 0; b < nbins; ++b)
+        if (!(b >= stride && stride > 0 && b % stride < giants)) heap.push({0, b});  // not a giant's tile-mate
     for (int32_t x : idx) {
         Item t = heap.top();
         heap.pop();
@@ -400,6 +419,16 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     }
     lap(on_device ? "degrees (device)" : "degrees");
     std::vector<int32_t> ubin, ibin;
+    // An item whose chain alone (count x cycles per dependent step) comes to 0.8 of the work-bound estimate
+    // of the epoch (the model choose_geometry() picks W with) is on or near the critical path: lpt_assign
+    // gives it a tile of its own.
+    int64_t giant_min = 0;
+    {
+        const double np = (double)std::min<int64_t>(B, std::max(1, prm.n_cu));
+        const double passes = std::ceil((double)B / (double)std::max(1, prm.n_cu));
+        const double t_rest = 48.0 * (4.0 / geo.G) * (double)n / np + 12000.0 * (double)B * passes;
+        giant_min = (int64_t)(0.8 * t_rest / (170.0 + 2.0 * geo.L));
+    }
     {
         // users and items are independent: one thread each (the LPT itself is a sequential heap walk)
         std::exception_ptr failed_u;
@@ -411,7 +440,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             }
         });
         try {
-            lpt_assign(degi, B * W, ibin);
+            lpt_assign(degi, B * W, ibin, prm.lone_giants && !std::getenv("MFSGD_NO_LONE_GIANTS") ? B : 0,
+                       giant_min);  // (the variable: A/B measurements)
         } catch (...) {
             tu.join();
             throw;
@@ -864,17 +894,20 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             lim_s = max_s;
             lim_r = max_r;
         } else {
-            const int64_t s_hi = std::min(max_s, (avail - min_rows) / 2);
             constexpr int kCand = 48;
             // per cell, once: the bytes it needs (an unpacked -- oversize -- cell: steps guessed from its rating count)
             std::vector<int64_t> need_s((size_t)ncell, 0), need_r((size_t)ncell, 0);
+            int64_t max_need_s = max_s;  // the cells that will be cut count too: when ONLY they are large (an item with
+                                         // a tile of its own), the candidates must not stop at the small cells' sizes
             for (int64_t c = 0; c < ncell; ++c) {
                 const CellOut& o = co[(size_t)c];
                 if (o.nu + o.ni == 0) continue;
                 need_r[(size_t)c] = rows_bytes_for(geo, (int)(o.nu + o.ni));
                 need_s[(size_t)c] = oversize[(size_t)c] ? sched_bytes_for(geo, W, (int)(o.nu + o.ni), o.n_order * 2 / G + 2)
                                                         : sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps);
+                max_need_s = std::max(max_need_s, need_s[(size_t)c]);
             }
+            const int64_t s_hi = std::min(max_need_s, (avail - min_rows) / 2);
             // the candidates are independent: one thread each, the winner (lowest cost, then lowest index) as before
             std::vector<double> cand_cost((size_t)kCand + 1, 0.0);
             std::vector<int64_t> cand_s((size_t)kCand + 1, 0), cand_r((size_t)kCand + 1, 0);

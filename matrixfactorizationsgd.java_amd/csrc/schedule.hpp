@@ -133,6 +133,7 @@ struct SchedParams {
     bool validated = false;
     bool solo = true;  // allow solo runs (MFSGD_FLAG_NO_SOLO clears it: A/B measurements, tests)
     bool device_pack = true;  // let the device pack the cells when it can (needs `ingest` with the packer)
+    bool lone_giants = true;  // an item that fills a fine bin by itself gets its tile to itself (schedule.cpp, lpt_assign)
 };
 
 struct Schedule {

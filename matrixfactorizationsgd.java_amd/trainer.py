@@ -215,11 +215,13 @@ class MatrixFactorizationSGD:
     def debug_epoch_profile(self):
         """[workgroups, 7] shader cycles per phase of one persistent epoch (diagnostic)."""
         info = self.schedule_info()
-        out = np.zeros(info["blocks"] * 8, np.uint64)
+        out = np.zeros(info["blocks"] * 16, np.uint64)
         n = C.c_int32()
         self._check(self._lib.mfsgd_debug_epoch_profile(self._handle(), _p(out, C.c_uint64), C.byref(n)))
-        self.last_slowest_cell = out[: n.value * 8].reshape(n.value, 8)[:, 7]  # longest single "ratings" phase per workgroup
-        return out[: n.value * 8].reshape(n.value, 8)[:, :7]
+        out = out[: n.value * 16].reshape(n.value, 16)
+        self.last_slowest_cell = out[:, 7]  # longest single "ratings" phase per workgroup
+        self.last_slowest_pass = out[:, 8:15]  # the seven phases of the pass that contained it
+        return out[:, :7]
 
     def debug_counters(self):
         out = np.zeros(4, np.int64)

@@ -275,3 +275,34 @@ def test_repeated_pairs_never_go_solo(mf, oracle):
         cells, rows, subs, entries = m.debug_schedule()
         # user sub-group holding users 5 and 9 has repeats; at most the other sub-group went solo
         assert int((subs[:, 0] >> 16).sum()) < U
+
+
+def test_item_with_a_tile_of_its_own(mf, oracle):
+    """An item whose chain of dependent updates is what the epoch waits for gets its tile to itself
+    (schedule.cpp, lpt_assign): the cells of that tile hold one item row and nothing but its ratings.  When
+    those cells are the ONLY large ones and have to be chunked (here: 600 users x 512-byte rows per cell),
+    the chunk limits must come out of their sizes, not of the small cells' (a regression: 11 219 chunks of
+    four rows, no solo run left)."""
+    rng = np.random.default_rng(1002)
+    U, I, k = 3000, 80, 100
+    u = list(range(U)) + list(rng.integers(0, U, 9000))
+    i = [7] * U + list(rng.integers(0, I, 9000))
+    key = rng.permutation(np.unique(np.array(u) * I + np.array(i)))
+    uu, ii, rr = key // I, key % I, rng.random(key.size) * 4 + 1
+    info = _check(mf, oracle, U, I, k, uu, ii, rr, blocks=5, waves=2)
+    assert info["split_cells"] >= 5 and info["chunks"] < 200, info
+    with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 3, blocks=5, waves=2) as m:
+        m.set_ratings(uu, ii, rr)
+        assert _solo_steps(m) == U
+        cells, rows, subs, entries = m.debug_schedule()
+        order, cell_ptr = m.order()
+    # the hot item's tile: every rating of its cells is a rating of item 7
+    ii = np.asarray(ii)
+    B = info["blocks"]
+    alone = 0
+    for c in range(B * B):
+        sel = order[cell_ptr[c]:cell_ptr[c + 1]]
+        if sel.size and (ii[sel] == 7).any():
+            assert (ii[sel] == 7).all(), c
+            alone += 1
+    assert alone == B

@@ -35,6 +35,7 @@ with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], 0.01, 0.05, 3, blocks=blo
     ms, _ = m.train_timed(5)
     prof = m.debug_epoch_profile().astype(np.float64)
     slowest = m.last_slowest_cell.astype(np.float64)
+    slowpass = m.last_slowest_pass.astype(np.float64)
 names = ["drain+issue", "tile wait", "barrier", "tile gather", "ratings", "publish", "own store"]
 tot = prof.sum(axis=1)
 nnz = info['nnz']
@@ -47,3 +48,5 @@ for k, nm in enumerate(names):
 print(f"  slowest cell's ratings phase per workgroup: mean {slowest.mean():.0f} max {slowest.max():.0f} cycles; "
       f"max_cell_steps {info['max_cell_steps']} -> {slowest.mean() / max(1, info['max_cell_steps']):.1f} cycles per step-equivalent; "
       f"sum of phases {tot.mean():.0f} cycles per epoch -> {tot.mean() / (ms / 5) / 1e6:.2f} GHz")
+print("  the pass with the slowest cell, per workgroup (mean cycles): " + ", ".join(f"{nm} {slowpass[:, k].mean():.0f}" for k, nm in enumerate(names))
+      + f"; total {slowpass.sum(axis=1).mean():.0f}")
