@@ -199,7 +199,11 @@ void default_item_map(mfsgd_handle* h) {
 // d_sync: done[B] words (kDoneStride apart), then {arrivals, generation, -, -} of the kernel's start-of-launch
 // barrier, then {abort code, launches that started, -, -}.  Zeroed once, when allocated; the kernel keeps it
 // consistent from launch to launch by itself.
-size_t sync_bytes(const Part& p) { return ((size_t)p.sched.B * kDoneStride + 8) * sizeof(unsigned); }
+// Behind them the tile mailboxes of the persistent kernel: B x kp granules of 8 bytes ({value, tag}; only tiles the
+// scheduler marked kCellLoneTile use theirs).
+size_t sync_bytes(const Part& p) {
+    return ((size_t)p.sched.B * kDoneStride + 8) * sizeof(unsigned) + (size_t)p.sched.B * (size_t)p.sched.geo.L * 4 * 8;
+}
 unsigned* abort_word(const Part& p) { return static_cast<unsigned*>(p.d_sync.p) + (size_t)p.sched.B * kDoneStride + 4; }
 
 int ensure_part_on_device(mfsgd_handle* h, Part& p) {

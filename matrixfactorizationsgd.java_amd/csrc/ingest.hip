@@ -94,10 +94,11 @@ __global__ void __launch_bounds__(256) degree_kernel(const int32_t* __restrict__
 __global__ void __launch_bounds__(256) key_kernel(const int32_t* __restrict__ u, const int32_t* __restrict__ i,
                                                   const int64_t n, const int32_t* __restrict__ ubin,
                                                   const int32_t* __restrict__ ibin, const int B, const int W,
-                                                  unsigned* __restrict__ key, unsigned* __restrict__ val) {
+                                                  const int giants, unsigned* __restrict__ key,
+                                                  unsigned* __restrict__ val) {
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
         const int fu = ubin[u[j]], fi = ibin[i[j]];
-        const int ub = fu % B, us = fu / B, it = fi % B, is = fi / B;
+        const int ub = fu % B, us = fi < giants ? 0 : fu / B, it = fi % B, is = fi / B;
         const int s = (is - us + W) % W;
         key[j] = (unsigned)((((long long)ub * B + it) * W + s) * W + us);
         val[j] = (unsigned)j;
@@ -153,7 +154,7 @@ fail:
 // Keys, one stable LSD radix sort of (key, index) pairs, bucket starts.  Leaves the sorted indices and
 // the bucket starts on the device (c->d_sorted, c->d_bptr).
 int bucket_on_device(Ctx* c, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
-                     int32_t U, int32_t I, int B, int W) {
+                     int32_t U, int32_t I, int B, int W, int giants) {
     const int64_t nb = (int64_t)B * B * W * W;
     if (n >= (int64_t)1 << 32 || nb >= (int64_t)1 << 32) return -1;
     if (!ensure_triples(c, u, i, n)) return -1;
@@ -175,7 +176,7 @@ int bucket_on_device(Ctx* c, const int32_t* u, const int32_t* i, int64_t n, cons
     ING_CHK(hipMalloc(&v0, 4 * nn));
     ING_CHK(hipMalloc(&v1, 4 * nn));
     ING_CHK(hipMalloc(&d_bptr, sizeof(long long) * (size_t)(nb + 1)));
-    hipLaunchKernelGGL(key_kernel, dim3(grid_for(n)), dim3(256), 0, 0, c->du, c->di, n, d_ubin, d_ibin, B, W, k0, v0);
+    hipLaunchKernelGGL(key_kernel, dim3(grid_for(n)), dim3(256), 0, 0, c->du, c->di, n, d_ubin, d_ibin, B, W, giants, k0, v0);
     ING_CHK(hipGetLastError());
     // LSD radix sort: stable, so equal keys keep their input order -- the host counting sort's order
     ING_CHK(rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, (size_t)n, 0u, bits, (hipStream_t)0));
@@ -234,16 +235,16 @@ int fetch_sorted32_cb(void* vctx, uint32_t* sorted) {
 }
 
 int bucket_dev_cb(void* vctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
-                  int32_t U, int32_t I, int B, int W, int64_t* bptr) {
+                  int32_t U, int32_t I, int B, int W, int giants, int64_t* bptr) {
     Ctx* c = static_cast<Ctx*>(vctx);
-    if (bucket_on_device(c, u, i, n, ubin, ibin, U, I, B, W) != 0) return -1;
+    if (bucket_on_device(c, u, i, n, ubin, ibin, U, I, B, W, giants) != 0) return -1;
     return fetch_bptr(c, bptr);
 }
 
 int bucket_cb(void* vctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
-              int32_t U, int32_t I, int B, int W, int64_t* bptr, int64_t* sorted) {
+              int32_t U, int32_t I, int B, int W, int giants, int64_t* bptr, int64_t* sorted) {
     Ctx* c = static_cast<Ctx*>(vctx);
-    if (bucket_on_device(c, u, i, n, ubin, ibin, U, I, B, W) != 0) return -1;
+    if (bucket_on_device(c, u, i, n, ubin, ibin, U, I, B, W, giants) != 0) return -1;
     const int rc = fetch_bptr(c, bptr) == 0 && fetch_sorted_cb(c, sorted) == 0 ? 0 : -1;
     drop_pack_state(c);
     return rc;

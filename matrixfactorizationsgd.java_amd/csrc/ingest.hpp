@@ -18,11 +18,12 @@ struct DeviceIngest {
                    int64_t* degi) = nullptr;
     // Stable sort of the rating indices by bucket key
     //   key = (((ub * B + it) * W + s) * W + us),  ub = ubin[u] % B, us = ubin[u] / B, it = ibin[i] % B,
-    //   is = ibin[i] / B, s = (is - us + W) % W
+    //   is = ibin[i] / B, s = (is - us + W) % W; an item with a tile of its own (ibin[i] < giants: schedule.cpp,
+    //   lpt_assign) takes us = 0 for all its ratings -- its tile holds nothing else, so its cells are ONE sub-cell
     // bptr[nb + 1] = first position of every bucket, sorted[n] = rating indices in key order (ties in
     // input order).  Returns 0 on success.
     int (*bucket)(void* ctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
-                  int32_t U, int32_t I, int B, int W, int64_t* bptr, int64_t* sorted) = nullptr;
+                  int32_t U, int32_t I, int B, int W, int giants, int64_t* bptr, int64_t* sorted) = nullptr;
     const struct DeviceIngestExt* ext = nullptr;  // the device packer, when available
 };
 
@@ -64,7 +65,7 @@ struct MixedPieces {
 struct DeviceIngestExt {
     // like DeviceIngest::bucket, but the sorted indices stay on the device (only bptr comes back)
     int (*bucket_dev)(void* ctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
-                      int32_t U, int32_t I, int B, int W, int64_t* bptr) = nullptr;
+                      int32_t U, int32_t I, int B, int W, int giants, int64_t* bptr) = nullptr;
     // the sorted indices after bucket_dev, for the host packer (fallback)
     int (*fetch_sorted)(void* ctx, int64_t* sorted) = nullptr;
     int (*fetch_sorted32)(void* ctx, uint32_t* sorted) = nullptr;  // the same, as the 32-bit indices the device holds

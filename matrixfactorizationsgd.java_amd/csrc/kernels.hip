@@ -619,12 +619,14 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     //    the abort word already set (an earlier launch of the same stream gave up) does nothing either.
     if (cx.tid == 0) {
         unsigned bad = __hip_atomic_load((gu32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned my_gen = 0;
         if (bad == 0u) {
             gu32* arrive = (gu32*)(abort_word - 4);
             gu32* gen = (gu32*)(abort_word - 3);
             for (int b = wg; b < B; b += NP)
                 __hip_atomic_store((gu32*)(done + (size_t)b * kFlagStride), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // before arriving
+            my_gen = (g0 + 1u) & 0xFFFFu;  // the same in every workgroup of this launch
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // my flags are zero before my arrival counts
             const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == (unsigned)NP - 1u) {
@@ -651,9 +653,21 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         }
         ctl[0] = bad != 0u ? 1u : 0u;
         ctl[1] = bad;
+        ctl[2] = my_gen;
     }
     wg_barrier();
     if (ctl[0] != 0) return;  // uniform; nothing has been modified
+    // Tile mailboxes (cells marked kCellLoneTile: a tile that is ONE item row in every cell -- the item whose chain
+    // the epoch waits for).  The row travels as KP granules {value, tag}, each written by ONE 8-byte sc1 store and
+    // read by ONE 8-byte sc1 load (a granule is never seen torn), tag = launch generation << 16 | round + 1: the
+    // consumer polls the granules themselves until every tag is the one it expects -- one memory round trip per
+    // hop, no drain, no flag, no gather -- and nothing of an earlier round or launch can be mistaken for it.
+    // Only the holder in the launch's LAST round stores the row to Q; the first round takes it from Q.
+    using gu64 = __attribute__((address_space(1))) unsigned long long;
+    gu64* const mbox = (gu64*)(abort_word + 4);
+    const unsigned tag_hi = ctl[2] << 16;
+    constexpr int KP = Cell<L, W, NH>::KP, ROWB = Cell<L, W, NH>::ROWB;
+    constexpr int NGR = KP >= 64 ? KP / 64 : 1;  // granules per lane of one wave
 
     // This workgroup's work list: (round R, block b) for b = blockIdx.x, +NP, ... in round order,
     // and within a cell its chunks in chain order.
@@ -720,8 +734,46 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (it1.R < n_rounds) cx.prefetch_schedule(cd1, (int)it1.idx, smem, buf ^ 1, sched_cap, rows, subs, entries);
         if (work) cx.gather(P, Q, 0, cx.nu);  // own rows: no dependency on other workgroups
+        // descriptor used two iterations from now: a scalar load issued here, in front of the wait for the tile,
+        // so that it completes in that wait's shadow (behind the tile gather it was exposed -- ~1.4 K cycles --
+        // whenever there was no gather to hide it: a tile taken from its mailbox)
+        const Item it2 = next_item(it1, cd1);
+        if (it2.R < n_rounds) cd2 = load_desc(cells, it2.idx);
         mark(0);  // drain of the previous stores + issue of the prefetch and the P gather
-        if (R > 0 && it0.first) {
+        const bool lone = KP >= 64 && (cd.rsv[0] & kCellLoneTile) != 0;  // uniform
+        if (R > 0 && it0.first && lone) {
+            // the tile is one row: take it from the tile's mailbox as soon as block b + 1 has posted it
+            if (cx.wave_all == 0) {
+                const unsigned tile = (unsigned)((b + R % B) % B);
+                const unsigned want = tag_hi | (unsigned)R;  // posted in round R - 1
+                const gu64* src = mbox + (size_t)tile * KP + cx.lane;
+                unsigned long long v[NGR];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < NGR; ++j) {
+                        v[j] = __hip_atomic_load(src + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (unsigned)(v[j] >> 32) == want;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 255u) == 0u) {
+                        if (__hip_atomic_load((gu32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                            spins > (1u << 22)) {
+                            if (cx.lane == 0) {
+                                __hip_atomic_store((gu32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ctl[0] = 1;
+                            }
+                            break;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NGR; ++j)
+                    *reinterpret_cast<unsigned*>(cx.lrows + (size_t)cx.nu * ROWB + (size_t)(cx.lane + 64 * j) * 4) = (unsigned)v[j];
+            }
+        } else if (R > 0 && it0.first) {
             // wait until block b + 1 has finished round R - 1 (it held our tile)
             if (cx.tid == 0) {
                 gu32* flag = (gu32*)(done + (size_t)((b + 1) % B) * kFlagStride);
@@ -753,15 +805,12 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
             return;
         }
         (void)0;
-        const Item it2 = next_item(it1, cd1);
+        const bool from_mbox = lone && R > 0;  // the row is in LDS already
 #ifdef MFSGD_ACQUIRE_HANDOFF
-        if (work) cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
+        if (work && !from_mbox) cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
 #else
-        if (work) cx.template gather<true>(P, Q, cx.nu, cx.nrows);  // the tile's q rows, sc1: stored by another CU
+        if (work && !from_mbox) cx.template gather<true>(P, Q, cx.nu, cx.nrows);  // the tile's q rows, sc1: stored by another CU
 #endif
-        // descriptor used two iterations from now: a scalar load issued here, behind every gather of
-        // this iteration, so that it completes in the shadow of the wait for the rows
-        if (it2.R < n_rounds) cd2 = load_desc(cells, it2.idx);
         if (work) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows (and the prefetched schedule) have landed
             wg_barrier();
@@ -771,7 +820,22 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
             mark(4);  // the ratings
             // write-through even when more chunks of this cell follow: item rows that no later
             // chunk touches have to be visible to the next workgroup all the same
-            cx.template scatter<true>(P, Q, cx.nu, cx.nrows);
+            if (lone && R + 1 < n_rounds) {
+                // post the row for block b - 1 (round R + 1); Q gets it from the holder in the last round
+                if (cx.wave_all == 0) {
+                    const unsigned tile = (unsigned)((b + R % B) % B);
+                    const unsigned long long tag = (unsigned long long)(tag_hi | (unsigned)(R + 1)) << 32;
+                    gu64* dst = mbox + (size_t)tile * KP + cx.lane;
+#pragma unroll
+                    for (int j = 0; j < NGR; ++j) {
+                        const unsigned bits =
+                            *reinterpret_cast<const unsigned*>(cx.lrows + (size_t)cx.nu * ROWB + (size_t)(cx.lane + 64 * j) * 4);
+                        __hip_atomic_store(dst + 64 * j, tag | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            } else {
+                cx.template scatter<true>(P, Q, cx.nu, cx.nrows);
+            }
         }
         // publish the tile: every storing wave drains, then one lane signals
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -20,10 +20,12 @@ struct CellDesc {
     uint16_t nu;       // distinct users  -> LDS slots [0, nu)
     uint16_t ni;       // distinct items  -> LDS slots [nu, nu + ni)
     uint32_t next;     // index of the cell's next chunk, 0 = this is the last one
-    uint32_t rsv[3];
+    uint32_t rsv[3];   // [0] bit 0 (kCellLoneTile): every cell of this cell's tile is ONE chunk holding ONE item row
+                       // -- the persistent kernel hands that row on through the tile's mailbox (kernels.hip)
 };
 static_assert(sizeof(CellDesc) == 32, "CellDesc layout");
 constexpr uint32_t kCellCritical = 0x80000000u;
+constexpr uint32_t kCellLoneTile = 1u;
 
 struct SubDesc {
     uint32_t off;  // first step, relative to the cell's first step (low 16 bits) | solo steps << 16

@@ -47,8 +47,9 @@ namespace {
 // gets its TILE to itself as well: the tile's other bins stay empty.  With nothing else in its tile, the
 // hand-off of that tile moves one row instead of a hundred and its cell holds no work but the chain.  (The giants are the first rows LPT
 // places, into bins 0, 1, ... in this order, so their tiles are known before anything else is placed.)
-void lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>& bin, int stride = 0,
-                int64_t giant_min = 0) {
+// Returns the number of such rows: they sit in bins 0 .. n - 1.
+int lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>& bin, int stride = 0,
+               int64_t giant_min = 0) {
     const int64_t n = (int64_t)deg.size();
     bin.assign((size_t)n, 0);
     std::vector<int32_t> idx;
@@ -78,6 +79,25 @@ void lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>
         bin[(size_t)x] = t.second;
         t.first += deg[(size_t)x];
         heap.push(t);
+    }
+    return giants;
+}
+
+// Marks the tiles whose cells all are a single chunk with exactly one item row (an item with a tile of its own,
+// lpt_assign): the persistent kernel passes that row from workgroup to workgroup through a mailbox of
+// self-validating {value, tag} granules instead of "store the tile, drain, flag" / "poll, gather" -- one
+// memory round trip per hop instead of two and a drain, on the hop the epoch waits for.  Rows shorter than one
+// wave of granules (fewer than 16 lanes per rating) are left alone.
+void mark_lone_tiles(std::vector<CellDesc>& cells, int B, const Geometry& geo) {
+    if (geo.L < 16 || B < 2 || std::getenv("MFSGD_NO_MAILBOX")) return;  // (the variable: A/B measurements)
+    for (int t = 0; t < B; ++t) {
+        bool lone = true;
+        for (int b = 0; b < B && lone; ++b) {
+            const CellDesc& d = cells[(size_t)b * B + t];
+            lone = d.next == 0 && d.ni == 1 && d.nu > 0 && (d.n_steps & 0x7FFFFFFFu) != 0;
+        }
+        if (lone)
+            for (int b = 0; b < B; ++b) cells[(size_t)b * B + t].rsv[0] |= kCellLoneTile;
     }
 }
 
@@ -423,6 +443,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     // of the epoch (the model choose_geometry() picks W with) is on or near the critical path: lpt_assign
     // gives it a tile of its own.
     int64_t giant_min = 0;
+    int giants = 0;  // items with a tile of their own: fine bins 0 .. giants - 1
     {
         const double np = (double)std::min<int64_t>(B, std::max(1, prm.n_cu));
         const double passes = std::ceil((double)B / (double)std::max(1, prm.n_cu));
@@ -440,8 +461,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             }
         });
         try {
-            lpt_assign(degi, B * W, ibin, prm.lone_giants && !std::getenv("MFSGD_NO_LONE_GIANTS") ? B : 0,
-                       giant_min);  // (the variable: A/B measurements)
+            giants = lpt_assign(degi, B * W, ibin, prm.lone_giants && !std::getenv("MFSGD_NO_LONE_GIANTS") ? B : 0,
+                                giant_min);  // (the variable: A/B measurements)
         } catch (...) {
             tu.join();
             throw;
@@ -457,7 +478,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     std::vector<int64_t> bptr((size_t)nb + 1, 0);
     auto bucket_of = [&](int64_t j) -> int64_t {
         const int32_t fu = ubin[(size_t)u[j]], fi = ibin[(size_t)i[j]];
-        const int ub = fu % B, us = fu / B, it = fi % B, is = fi / B;
+        // (an item with a tile of its own: all its ratings in the cell's first sub-cell -- the tile holds nothing
+        // else, so nothing of the same users runs beside it, and its chain is one run instead of W)
+        const int ub = fu % B, us = fi < giants ? 0 : fu / B, it = fi % B, is = fi / B;
         const int s = (is - us + W) % W;
         return (((int64_t)ub * B + it) * W + s) * W + us;
     };
@@ -468,14 +491,14 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                                      ? prm.ingest->ext
                                      : nullptr;
     bool sorted_on_device = false;
-    if (ext && ext->bucket_dev(prm.ingest->ctx, u, i, n, ubin.data(), ibin.data(), U, I, B, W, bptr.data()) == 0)
+    if (ext && ext->bucket_dev(prm.ingest->ctx, u, i, n, ubin.data(), ibin.data(), U, I, B, W, giants, bptr.data()) == 0)
         sorted_on_device = true;
     else
         ext = nullptr;
     if (!sorted_on_device) {
         sorted.resize((size_t)n);
-        if (on_device && prm.ingest->bucket(prm.ingest->ctx, u, i, n, ubin.data(), ibin.data(), U, I, B, W, bptr.data(),
-                                            sorted.data()) != 0) {
+        if (on_device && prm.ingest->bucket(prm.ingest->ctx, u, i, n, ubin.data(), ibin.data(), U, I, B, W, giants,
+                                            bptr.data(), sorted.data()) != 0) {
             on_device = false;
             std::fill(bptr.begin(), bptr.end(), 0);
         }
@@ -591,6 +614,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 sch.max_cell_rows = std::max<int64_t>(sch.max_cell_rows, ci.nu + ci.ni);
                 sch.max_cell_steps = std::max<int64_t>(sch.max_cell_steps, ci.crit);
             }
+            mark_lone_tiles(sch.cells, B, geo);
             sch.sched_cap = (int)max_s;
             sch.lds_bytes = (int)((16 + 2 * max_s + max_r + 15) & ~(int64_t)15);
             sch.total_rows = tot_rows;
@@ -907,16 +931,21 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                                                         : sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps);
                 max_need_s = std::max(max_need_s, need_s[(size_t)c]);
             }
+            // two grids: up to the largest cell that fits as it is (where the optimum usually sits), and from there
+            // up to the largest cell there is
+            const int64_t s_mid = std::min(max_s, (avail - min_rows) / 2);
             const int64_t s_hi = std::min(max_need_s, (avail - min_rows) / 2);
+            const int n_cand = s_hi > s_mid ? 2 * kCand : kCand;
             // the candidates are independent: one thread each, the winner (lowest cost, then lowest index) as before
-            std::vector<double> cand_cost((size_t)kCand + 1, 0.0);
-            std::vector<int64_t> cand_s((size_t)kCand + 1, 0), cand_r((size_t)kCand + 1, 0);
+            std::vector<double> cand_cost((size_t)n_cand + 1, 0.0);
+            std::vector<int64_t> cand_s((size_t)n_cand + 1, 0), cand_r((size_t)n_cand + 1, 0);
             std::atomic<int> next_cand{0};
             auto eval = [&]() {
                 for (;;) {
                     const int x = next_cand.fetch_add(1);
-                    if (x > kCand) break;
-                    int64_t S = min_sched + (s_hi - min_sched) * x / kCand;
+                    if (x > n_cand) break;
+                    int64_t S = x <= kCand ? min_sched + (s_mid - min_sched) * x / kCand
+                                           : s_mid + (s_hi - s_mid) * (x - kCand) / kCand;
                     S = (S + 15) & ~(int64_t)15;
                     if (S > (avail - min_rows) / 2) S = ((avail - min_rows) / 2) & ~(int64_t)15;
                     const int64_t R = (avail - 2 * S) & ~(int64_t)15;
@@ -935,12 +964,12 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             };
             {
                 std::vector<std::thread> th;
-                for (int t = 1; t < std::min(nthreads, kCand + 1); ++t) th.emplace_back(eval);
+                for (int t = 1; t < std::min(nthreads, n_cand + 1); ++t) th.emplace_back(eval);
                 eval();
                 for (auto& t : th) t.join();
             }
             double best_cost = -1;
-            for (int x = 0; x <= kCand; ++x)
+            for (int x = 0; x <= n_cand; ++x)
                 if (best_cost < 0 || cand_cost[(size_t)x] < best_cost) {
                     best_cost = cand_cost[(size_t)x];
                     lim_s = cand_s[(size_t)x];
@@ -1098,6 +1127,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             out.max_cell_steps = std::max(out.max_cell_steps, crit_c);
         }
     }
+    mark_lone_tiles(out.cells, B, geo);
     lap("  offsets");
     {
         sched_cap = std::max(sched_cap, min_sched);

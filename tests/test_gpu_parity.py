@@ -774,6 +774,36 @@ def test_native_dsgd_world1_self_ring(mf, oracle, m, k):
     assert np.array_equal(P1, Po)
 
 
+@pytest.mark.parametrize("k,B", [(64, 16), (64, 40), (128, 16), (256, 24), (100, 12)])
+def test_lone_tile_mailbox_hand_off(mf, oracle, monkeypatch, k, B):
+    """An item with a tile of its own travels from workgroup to workgroup through the tile's mailbox ({value, tag}
+    granules, kernels.hip run_ring) instead of store + flag + gather: factors and RMSE bit-exact against the
+    oracle over several epochs (every epoch is a launch of its own: the tags carry the launch generation), for
+    one, two and four granules per lane, in a graph replay and in eager launches; and the same schedule with the
+    mailbox switched off (MFSGD_NO_MAILBOX) gives the same bits."""
+    from mfsgd_amd import _lib
+
+    rng = np.random.default_rng(k + B)
+    U, I = 150 * B, 90
+    u = list(range(U)) + list(range(0, U, 2)) + list(rng.integers(0, U, 6 * U))
+    i = [9] * U + [17] * (U // 2) + list(rng.integers(0, I, 6 * U))  # item 9 rated by everybody, item 17 by every other user
+    key = rng.permutation(np.unique(np.array(u) * I + np.array(i)))
+    uu, ii, rr = key // I, key % I, (rng.random(key.size) * 4 + 1).astype(np.float32)
+    got = []
+    for flags, off in ((0, False), (_lib.FLAG_NO_GRAPH, False), (0, True)):
+        if off:
+            monkeypatch.setenv("MFSGD_NO_MAILBOX", "1")
+        with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 5, blocks=B, waves=2, flags=flags) as m:
+            m.set_ratings(uu, ii, rr)
+            n_lone = int((m.debug_schedule()[0][:, 5] & 1).sum())
+            assert (n_lone == 0) if off else (n_lone >= B and n_lone % B == 0), (n_lone, off)
+            assert m.debug_counters()["persistent_parts"] in (0, 1)
+        rm, info = _run(mf, oracle, U, I, k, uu, ii, rr, seed=5, epochs=4, blocks=B, waves=2, flags=flags)
+        assert info["split_cells"] == 0
+        got.append(rm)
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+
+
 @pytest.mark.parametrize("world,m", [(2, 1), (3, 1), (2, 2)])
 def test_native_dsgd_multi_process_shm(mf, oracle, tmp_path, monkeypatch, world, m):
     """The ring under the C-ABI with SEVERAL REAL PROCESSES (world 2 and 3, one and two partitions per rank):

@@ -306,3 +306,39 @@ def test_item_with_a_tile_of_its_own(mf, oracle):
             assert (ii[sel] == 7).all(), c
             alone += 1
     assert alone == B
+
+
+def test_lone_tiles_are_marked_for_the_mailbox_hand_off(mf, oracle):
+    """A tile that is one item row, one chunk, in EVERY cell carries kCellLoneTile (CellDesc.rsv[0] bit 0) in all
+    its cells -- the persistent kernel passes such a row on through the tile's mailbox; no other cell carries it,
+    and a tile whose cells had to be chunked does not either."""
+    rng = np.random.default_rng(77)
+    U, I, k, B = 800, 60, 64, 4
+    u = list(range(U)) + list(rng.integers(0, U, 3000))
+    i = [9] * U + list(rng.integers(0, I, 3000))
+    key = rng.permutation(np.unique(np.array(u) * I + np.array(i)))
+    uu, ii, rr = key // I, key % I, rng.random(key.size) * 4 + 1
+    _check(mf, oracle, U, I, k, uu, ii, rr, blocks=B, waves=2)
+    with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 3, blocks=B, waves=2) as m:
+        m.set_ratings(uu, ii, rr)
+        cells = m.debug_schedule()[0]
+        order, cell_ptr = m.order()
+    assert cells.shape[0] == B * B, "nothing chunked here"
+    lone = (cells[:, 5] & 1).reshape(B, B)  # [block, tile]
+    tiles = np.flatnonzero(lone.all(axis=0))
+    assert tiles.size == 1 and lone.sum() == B, lone
+    for c in range(B * B):  # canonical order: rounds, then blocks; block b holds tile (b + round) % B
+        rnd, b = divmod(c, B)
+        sel = order[cell_ptr[c]:cell_ptr[c + 1]]
+        if (b + rnd) % B == tiles[0]:
+            assert sel.size and (np.asarray(ii)[sel] == 9).all(), c
+        else:
+            assert not (np.asarray(ii)[sel] == 9).any(), c
+    # rows too short for a wave of granules (k <= 32), or a giant whose cells are chunked: not marked
+    for kk, UU in ((32, 800), (256, 3000)):
+        u2 = list(range(UU)) + list(rng.integers(0, UU, 3000))
+        i2 = [9] * UU + list(rng.integers(0, I, 3000))
+        key = np.unique(np.array(u2) * I + np.array(i2))
+        with mf.MatrixFactorizationSGD(UU, I, kk, LR, LAM, 3, blocks=B, waves=2) as m:
+            m.set_ratings(key // I, key % I, rng.random(key.size) * 4 + 1)
+            assert (m.debug_schedule()[0][:, 5] & 1).sum() == 0, kk
