@@ -88,10 +88,11 @@ int lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>&
 // self-validating {value, tag} granules instead of "store the tile, drain, flag" / "poll, gather" -- one
 // memory round trip per hop instead of two and a drain, on the hop the epoch waits for.  Rows shorter than one
 // wave of granules (fewer than 16 lanes per rating) are left alone.
-void mark_lone_tiles(std::vector<CellDesc>& cells, int B, const Geometry& geo) {
+// `tile_items[t]`: rated items of tile t -- one item row per cell is not enough, it has to be the SAME row in all of them.
+void mark_lone_tiles(std::vector<CellDesc>& cells, int B, const Geometry& geo, const std::vector<int32_t>& tile_items) {
     if (geo.L < 16 || B < 2 || std::getenv("MFSGD_NO_MAILBOX")) return;  // (the variable: A/B measurements)
     for (int t = 0; t < B; ++t) {
-        bool lone = true;
+        bool lone = tile_items[(size_t)t] == 1;
         for (int b = 0; b < B && lone; ++b) {
             const CellDesc& d = cells[(size_t)b * B + t];
             lone = d.next == 0 && d.ni == 1 && d.nu > 0 && (d.n_steps & 0x7FFFFFFFu) != 0;
@@ -472,6 +473,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     }
     lap("LPT partition");
     // fine bin f -> block f % B, sub-group f / B
+    std::vector<int32_t> tile_items((size_t)B, 0);  // rated items per tile (mark_lone_tiles)
+    for (int32_t x = 0; x < I; ++x)
+        if (degi[(size_t)x] > 0) tile_items[(size_t)(ibin[(size_t)x] % B)]++;
 
     // ---- counting sort by (cell, sub-round, wave) ---------------------------
     const int64_t nb = (int64_t)B * B * W * W;
@@ -614,7 +618,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 sch.max_cell_rows = std::max<int64_t>(sch.max_cell_rows, ci.nu + ci.ni);
                 sch.max_cell_steps = std::max<int64_t>(sch.max_cell_steps, ci.crit);
             }
-            mark_lone_tiles(sch.cells, B, geo);
+            mark_lone_tiles(sch.cells, B, geo, tile_items);
             sch.sched_cap = (int)max_s;
             sch.lds_bytes = (int)((16 + 2 * max_s + max_r + 15) & ~(int64_t)15);
             sch.total_rows = tot_rows;
@@ -1127,7 +1131,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             out.max_cell_steps = std::max(out.max_cell_steps, crit_c);
         }
     }
-    mark_lone_tiles(out.cells, B, geo);
+    mark_lone_tiles(out.cells, B, geo, tile_items);
     lap("  offsets");
     {
         sched_cap = std::max(sched_cap, min_sched);

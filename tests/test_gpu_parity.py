@@ -804,6 +804,16 @@ def test_lone_tile_mailbox_hand_off(mf, oracle, monkeypatch, k, B):
     assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
 
 
+def test_two_items_sharing_a_tile_do_not_use_the_mailbox(mf, oracle):
+    """One item row per cell is not "a tile of one row": items 1 and 2 share a tile and are rated from different
+    blocks (found by tests/gpu_fuzz_extra.py case 263 while the mailbox hand-off was being written)."""
+    from tests.test_schedule_cpu import _two_items_one_tile
+
+    U, I, u, i, r = _two_items_one_tile()
+    for k in (64, 128):
+        _run(mf, oracle, U, I, k, u, i, r, epochs=3, blocks=2, waves=1)
+
+
 @pytest.mark.parametrize("world,m", [(2, 1), (3, 1), (2, 2)])
 def test_native_dsgd_multi_process_shm(mf, oracle, tmp_path, monkeypatch, world, m):
     """The ring under the C-ABI with SEVERAL REAL PROCESSES (world 2 and 3, one and two partitions per rank):

@@ -21,6 +21,19 @@ def _check(mf, oracle, U, I, k, u, i, r, replay=True, **kw):
         sched = m.debug_schedule()
     assert info["nnz"] == u.size
     assert oracle.check_block_schedule(u, i, U, I, order, cell_ptr, info["rounds"], info["blocks"]) == 0
+    # tiles marked for the mailbox hand-off (CellDesc.rsv[0] bit 0): ONE item, the same in every cell of the tile, every
+    # cell a single chunk with work (a regression: "one item row per cell" alone let two items share such a tile)
+    B = info["blocks"]
+    if B >= 1 and sched[0].shape[0] >= B * B and not info["swapped"]:
+        lone = (sched[0][: B * B, 5] & 1).reshape(B, B)  # [block, tile]
+        tile_item = {}
+        for c in range(B * B):  # canonical order: rounds, then blocks; block b holds tile (b + round) % B
+            rnd, b = divmod(c, B)
+            t = (b + rnd) % B
+            if lone[b, t]:
+                assert lone[:, t].all() and sched[0][b * B + t, 4] == 0, (b, t)
+                items = np.unique(i[order[cell_ptr[c]:cell_ptr[c + 1]]])
+                assert items.size == 1 and tile_item.setdefault(t, items[0]) == items[0], (b, t, items)
     if replay and u.size:
         P, Q = oracle.init_factors(U, I, k, 3)
         Pe, Qe = P.copy(), Q.copy()
@@ -342,3 +355,32 @@ def test_lone_tiles_are_marked_for_the_mailbox_hand_off(mf, oracle):
         with mf.MatrixFactorizationSGD(UU, I, kk, LR, LAM, 3, blocks=B, waves=2) as m:
             m.set_ratings(key // I, key % I, rng.random(key.size) * 4 + 1)
             assert (m.debug_schedule()[0][:, 5] & 1).sum() == 0, kk
+
+
+def _two_items_one_tile():
+    """Items 1 and 2 share a tile, each rated by one user of a different block: every cell of that tile holds ONE
+    item row -- but not the same one.  (Found by tests/gpu_fuzz_extra.py: such a tile was handed on through the
+    mailbox as if it were one row.)"""
+    u = np.array([2, 3, 4, 0, 1], np.int32)
+    i = np.array([0, 0, 0, 1, 2], np.int32)
+    r = np.array([4.0, 3.0, 5.0, 2.0, 1.0], np.float32)
+    return 5, 3, u, i, r
+
+
+def test_two_items_in_a_tile_are_not_a_lone_tile(mf, oracle):
+    U, I, u, i, r = _two_items_one_tile()
+    info = _check(mf, oracle, U, I, 64, u, i, r, blocks=2, waves=1)  # (_check verifies what the marked tiles hold)
+    with mf.MatrixFactorizationSGD(U, I, 64, LR, LAM, 3, blocks=2, waves=1) as m:
+        m.set_ratings(u, i, r)
+        cells = m.debug_schedule()[0]
+        order, cell_ptr = m.order()
+    # the situation the test is about did arise: a tile whose two cells hold one item each, different ones
+    per_tile = {}
+    for c in range(4):
+        rnd, b = divmod(c, 2)
+        per_tile.setdefault((b + rnd) % 2, []).append(sorted(set(i[order[cell_ptr[c]:cell_ptr[c + 1]]].tolist())))
+    shared = [t for t, v in per_tile.items() if sorted(v) == [[1], [2]]]
+    assert len(shared) == 1, per_tile
+    lone = (cells[:, 5] & 1).reshape(2, 2)  # [block, tile]
+    assert not lone[:, shared[0]].any()
+    assert lone[:, 1 - shared[0]].all()  # the other tile IS one item (item 0), rated from both blocks
