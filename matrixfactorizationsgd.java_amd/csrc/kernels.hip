@@ -441,7 +441,7 @@ struct Cell {
                 if (t < nr) run_step(A, B, eptr, 2 * G);
                 if constexpr (TRAIN) lds_st(lr_, rqa, rq);
             }
-            if (nsolo > 0) {
+            if (TRAIN && nsolo > 0) {
                 // Solo run: header record, then one 16-byte record per step {lr*r, next slots, mailbox, r}.
                 const uint4* hdr = lent + (size_t)((offs & 0xFFFF) + n + nr + kSoloPad) * G;
                 const unsigned s0 = hdr->y;
@@ -467,20 +467,8 @@ struct Cell {
                         pa = ((e.y & 0xFFFFu) << 4) + lo;
                     }
                     lds_st(lr_, rqa, q);
-                } else {
-                    // RMSE: nothing is written, so lane group g takes steps g, g + G, ... (the address of step
-                    // t sits in record t - 1; groups past the end read the zero row with r = 0)
-                    const float4 q = lds_ld(lr_, rqa);
-                    for (int t0 = 0; t0 < nsolo; t0 += G) {
-                        const int t = t0 + g;
-                        const bool live = t < nsolo;
-                        const uint4 e = hdr[1 + (live ? t : nsolo)];  // past the end: the terminator (r = 0)
-                        const unsigned sl = hdr[live ? t : nsolo].y;    // ... whose predecessor addresses the zero row
-                        const float4 p = lds_ld(lr_, ((sl & 0xFFFFu) << 4) + lo);
-                        const float err = __builtin_bit_cast(float, e.w) - group_allreduce<L>(chunk_dot(p, q));
-                        acc += (double)err * (double)err;
-                    }
                 }
+                // (RMSE: the solo records of ALL sub-cells are shared out over all waves below)
             }
             if constexpr (TIMED) {
                 tm2 = __builtin_amdgcn_s_memtime();
@@ -493,6 +481,30 @@ struct Cell {
                 }
             }
             if constexpr (TRAIN) wg_barrier();
+        }
+        if constexpr (!TRAIN) {
+            // RMSE over the solo records: nothing is written, so the records of EVERY sub-cell are dealt out over
+            // all waves of the workgroup and, inside a wave, lane group g takes record t0 + g (the address of
+            // step t sits in record t - 1; groups past the end read the terminator: the zero row with r = 0).
+            // (A cell that is one solo run -- an item with a tile of its own -- would otherwise be one wave's job.)
+            for (int sc = 0; sc < W * W; ++sc) {
+                const uint2 sd = lsub[sc];
+                const int offs = __builtin_amdgcn_readfirstlane((int)sd.x);
+                const int nsolo = (int)((unsigned)offs >> 16);
+                if (nsolo == 0) continue;
+                const int nall = __builtin_amdgcn_readfirstlane((int)sd.y);
+                const uint4* hdr = lent + (size_t)((offs & 0xFFFF) + (nall & 0xFFFF) + (int)((unsigned)nall >> 16) + kSoloPad) * G;
+                const float4 q = lds_ld(lr_, (__builtin_amdgcn_ubfe(hdr->y, 16, 15) << 4) + lo);
+                for (int t0 = wave_all * G; t0 < nsolo; t0 += NWV * G) {
+                    const int t = t0 + g;
+                    const bool live = t < nsolo;
+                    const uint4 e = hdr[1 + (live ? t : nsolo)];  // past the end: the terminator (r = 0)
+                    const unsigned sl = hdr[live ? t : nsolo].y;    // ... whose predecessor addresses the zero row
+                    const float4 p = lds_ld(lr_, ((sl & 0xFFFFu) << 4) + lo);
+                    const float err = __builtin_bit_cast(float, e.w) - group_allreduce<L>(chunk_dot(p, q));
+                    acc += (double)err * (double)err;
+                }
+            }
         }
     }
 };
