@@ -67,24 +67,30 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
 // `ea`: LDS byte address of the run's header record, `rowbase`: LDS byte address of row slot 0 plus
 // this lane's 16-byte offset inside a row, n >= 1 steps, c2 = {c, c} as one 64-bit scalar.
 template <int L>
-__device__ __forceinline__ void solo_chain_asm(const float4 rq, const unsigned ea, const unsigned rowbase, int n,
+__device__ __forceinline__ void solo_chain_asm(float4& rq, const unsigned ea, const unsigned rowbase, int n,
                                                const float lr, const uint64_t c2) {
     static_assert(L == 16 || L == 32 || L == 64, "solo loops: 16, 32 or 64 lanes per rating");
     using f4 = __attribute__((ext_vector_type(4))) float;
-    const f4 q = {rq.x, rq.y, rq.z, rq.w};
+    f4 q = {rq.x, rq.y, rq.z, rq.w};
+    n = __builtin_amdgcn_readfirstlane(n);
     constexpr int PADV = mfsgd_pad_chain(L);
     if constexpr (L == 16)
-        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT("", MFSGD_SFMA_V) MFSGD_SOLO_CHAIN_OPERANDS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT("", MFSGD_SFMA2_V) MFSGD_SOLO_CHAIN_OPERANDS);
     else if constexpr (L == 32)
-        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_SWAP_ADD16, MFSGD_SFMA_V) MFSGD_SOLO_CHAIN_OPERANDS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_SWAP_ADD16, MFSGD_SFMA2_V) MFSGD_SOLO_CHAIN_OPERANDS);
     else
-        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_BCAST_ADD64, MFSGD_SFMA_S) MFSGD_SOLO_CHAIN_OPERANDS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_BCAST_ADD64, MFSGD_SFMA2_S) MFSGD_SOLO_CHAIN_OPERANDS);
+    rq = make_float4(q[0], q[1], q[2], q[3]);  // q after the n steps (the helper stores it; the caller needs it when it cuts a run)
 }
 // Returns false if it gave up waiting for the chain wave (bounded polling; cannot happen with a
 // schedule the packer built -- the bound only keeps a corrupt one from hanging the GPU).
 template <int L>
-__device__ __forceinline__ bool solo_helper_asm(const unsigned ea, const unsigned rowbase, int n, const uint64_t c2) {
+__device__ __forceinline__ bool solo_helper_asm(const unsigned ea, const unsigned rowbase, int n, const uint64_t c2,
+                                                int fin = 1) {  // fin = 0: do not store q at the end (ubench3's cut runs)
     constexpr int PADV = mfsgd_pad_helper(L);
+    n = __builtin_amdgcn_readfirstlane(n);  // (workgroup-uniform by construction; the compiler cannot always see it)
+    fin = __builtin_amdgcn_readfirstlane(fin);
+    asm volatile("" : "+s"(fin));  // a register, not an immediate, in the text below
     int spins = 1 << 22;
     asm volatile(MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_OPERANDS);
     return spins != 0;
@@ -304,15 +310,22 @@ struct Cell {
                 // redoes the q recurrence and does all the stores (run_asm.hpp).
                 for (int s = 0; s < W; ++s) {
                     if constexpr (L >= 16) {
-                        const uint2 sd = lsub[s * W + (wave + 1) % W];
-                        const int ns = __builtin_amdgcn_readfirstlane((int)(sd.x >> 16));
-                        if (ns > 0) {
+                        const uint64_t c2 = ((uint64_t)__builtin_bit_cast(unsigned, c) << 32) | __builtin_bit_cast(unsigned, c);
+                        const unsigned rowbase = (unsigned)(uintptr_t)(lptr_t)lr_ + lo;
+                        // header record of apply wave a's solo run in this sub-round, and its length
+                        auto run_of = [&](const int a, int& ns) -> const uint4* {
+                            const uint2 sd = lsub[s * W + a];
+                            ns = __builtin_amdgcn_readfirstlane((int)(sd.x >> 16));
                             const int first = __builtin_amdgcn_readfirstlane((int)((sd.x & 0xFFFFu) + (sd.y & 0xFFFFu) + (sd.y >> 16))) + kSoloPad;
-                            const uint4* hdr = lent + (size_t)first * G;
-                            const uint64_t c2 = ((uint64_t)__builtin_bit_cast(unsigned, c) << 32) | __builtin_bit_cast(unsigned, c);
-                            if (!solo_helper_asm<L>((unsigned)(uintptr_t)(lptr_t)hdr, (unsigned)(uintptr_t)(lptr_t)lr_ + lo, ns, c2))
-                                if (fail_flag) *fail_flag = 1;
-                        }
+                            return lent + (size_t)first * G;
+                        };
+                        int ns;
+                        const uint4* hdr = run_of((wave + 1) % W, ns);
+                        // (cutting a long run in two and giving the second half to a second, idle copy wave was
+                        // measured -- tools/ubench3 mode 4: 128.7 against 133.5 cycles per step at 16 lanes, no gain
+                        // at 32 / 64; in situ 4.120 against 4.125 ms per epoch -- and is not done)
+                        if (ns > 0 && !solo_helper_asm<L>((unsigned)(uintptr_t)(lptr_t)hdr, rowbase, ns, c2) && fail_flag)
+                            *fail_flag = 1;
                     }
                     wg_barrier();
                 }
@@ -449,8 +462,9 @@ struct Cell {
                 if constexpr (TRAIN && NH > 0 && L >= 16) {
                     // chain wave: dot -> s -> q' only; its helper (a copy wave) stores the p rows and q
                     const uint64_t c2 = ((uint64_t)__builtin_bit_cast(unsigned, c) << 32) | __builtin_bit_cast(unsigned, c);
-                    solo_chain_asm<L>(lds_ld(lr_, rqa), (unsigned)(uintptr_t)(lptr_t)hdr, (unsigned)(uintptr_t)(lptr_t)lr_ + lo,
-                                      nsolo, lr, c2);
+                    const unsigned rowbase = (unsigned)(uintptr_t)(lptr_t)lr_ + lo;
+                    float4 q = lds_ld(lr_, rqa);
+                    solo_chain_asm<L>(q, (unsigned)(uintptr_t)(lptr_t)hdr, rowbase, nsolo, lr, c2);
                 } else if constexpr (TRAIN) {
                     // one wave does everything (kernels without copy waves); every lane group computes the
                     // same step -- the chain is sequential -- and they all store the same bits

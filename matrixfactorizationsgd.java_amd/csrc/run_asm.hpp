@@ -17,7 +17,14 @@
 // an operand (SGPR pair {c, c}), not part of the entry.  Arithmetic is, instruction for
 // instruction, DESIGN.md section 3: the pair of waves produces the bits Cell::solo_generic does.
 //
-// Shared with tools/ubench3.hip, which times the two loops against each other in isolation.
+// [r2, late] s of an even and the following odd step are posted TOGETHER (one ds_write2_b32 behind the odd
+// step; a last odd-numbered step is posted alone): the chain wave issues half an LDS write per step less.
+// (A long run can be cut in two -- the chain wave stores q into its LDS row between the halves, a second copy wave
+// follows the second half from there and the first helper leaves q alone, %[fin] = 0: tools/ubench3 mode 4.  Measured
+// and not used by the product: the helper is the slower of the pair at 16 lanes per rating, but a third wave on the
+// LDS slows the chain wave by what the second helper gains.)
+//
+// Shared with tools/ubench3.hip, which times the loops against each other in isolation.
 #pragma once
 
 // The loops below are a few 64-byte instruction-cache lines long and their cycle count per pass depends on
@@ -38,7 +45,7 @@ constexpr int mfsgd_pad_chain(int lanes) {
 #ifdef MFSGD_PAD_CHAIN
     return MFSGD_PAD_CHAIN;
 #else
-    return lanes == 32 ? 0 : 4;
+    return lanes == 32 ? 2 : 0;  // (the loop that posts s in pairs; the table above is the earlier one-post-per-step loop)
 #endif
 }
 constexpr int mfsgd_pad_helper(int lanes) {
@@ -158,6 +165,9 @@ constexpr int mfsgd_pad_helper(int lanes) {
 // MFSGD_BCAST_ADD64 -- in vcc_lo, with lr in v131 (one scalar operand per VALU instruction on gfx9)
 #define MFSGD_SFMA_V(LRR) "v_fma_f32 v130, -%[lr], v132, v" LRR "\n\t"
 #define MFSGD_SFMA_S(LRR) "v_fma_f32 v130, -v131, vcc_lo, v" LRR "\n\t"
+// the same with the destination named (the solo chain keeps s of an even and an odd step apart)
+#define MFSGD_SFMA2_V(S, LRR) "v_fma_f32 v" S ", -%[lr], v132, v" LRR "\n\t"
+#define MFSGD_SFMA2_S(S, LRR) "v_fma_f32 v" S ", -v131, vcc_lo, v" LRR "\n\t"
 #define MFSGD_RUN_LOOP_ASM_OPERANDS                                                                                   \
     : [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [n] "+s"(pairs)                              \
     : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [e1] "n"(EST), [e2] "n"(2 * EST), [e3] "n"(3 * EST),              \
@@ -174,8 +184,8 @@ constexpr int mfsgd_pad_helper(int lanes) {
 // v[100:103] q (updated in place); v[104:107] / v[108:111] p row of the even / odd step (prefetched
 // a step ahead); v[116:117] / v[118:119] {lr*r, next slots} of the even / odd step; v113 p address;
 // v[120:121] chunk products, v132 dot, v[122:125] c*q, v130 s.
-#define MFSGD_SOLO_CHAIN_HALF(P0, P1, P2, P3, N0, N1, N2, N3, ELRR, ESLOT, NEXTE, OFF_NEXT, OFF_MBOX, EXTRA, SFMA) \
-        "s_waitcnt lgkmcnt(1)\n\t" \
+#define MFSGD_SOLO_CHAIN_HALF(P0, P1, P2, P3, N0, N1, N2, N3, ELRR, ESLOT, NEXTE, OFF_NEXT, WAIT, S, S1, EXTRA, SFMA) \
+        "s_waitcnt lgkmcnt(" WAIT ")\n\t" \
         "v_pk_mul_f32 v[120:121], v[" P0 ":" P1 "], v[100:101]\n\t" \
         "v_pk_fma_f32 v[120:121], v[" P2 ":" P3 "], v[102:103], v[120:121]\n\t" \
         "v_add_f32 v132, v120, v121\n\t" \
@@ -188,15 +198,13 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "ds_read_b64 v[" NEXTE "], v138 offset:" OFF_NEXT "\n\t" \
         "s_nop 0\n\t" \
         "v_add_f32_dpp v132, v132, v132 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "s_nop 1\n\t" \
+        "s_sub_u32 %[n], %[n], 1\n\t" \
+        "s_cmp_eq_u32 %[n], 0\n\t" \
         "v_add_f32_dpp v132, v132, v132 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
         EXTRA \
-        SFMA(ELRR) \
-        "v_pk_fma_f32 v[100:101], v[130:131], v[" P0 ":" P1 "], v[122:123] op_sel_hi:[0,1,1]\n\t" \
-        "v_pk_fma_f32 v[102:103], v[130:131], v[" P2 ":" P3 "], v[124:125] op_sel_hi:[0,1,1]\n\t" \
-        "s_sub_u32 %[n], %[n], 1\n\t" \
-        "ds_write_b32 v138, v130 offset:" OFF_MBOX "\n\t" \
-        "s_cmp_eq_u32 %[n], 0\n\t"
+        SFMA(S, ELRR) \
+        "v_pk_fma_f32 v[100:101], v[" S ":" S1 "], v[" P0 ":" P1 "], v[122:123] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 v[102:103], v[" S ":" S1 "], v[" P2 ":" P3 "], v[124:125] op_sel_hi:[0,1,1]\n\t"
 
 // `ea` = LDS byte address of the header entry; n >= 1 steps.
 #define MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA, SFMA) \
@@ -217,21 +225,28 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "v_add_u32 v138, 16, v138\n\t" \
         MFSGD_LOOP_ALIGN \
         "1:\n\t" \
-        MFSGD_SOLO_CHAIN_HALF("104", "105", "106", "107", "108", "109", "110", "111", "116", "117", "118:119", "16", "8", EXTRA, SFMA) \
+        MFSGD_SOLO_CHAIN_HALF("104", "105", "106", "107", "108", "109", "110", "111", "116", "117", "118:119", "16", "1", "130", "131", EXTRA, SFMA) \
         "s_cbranch_scc1 2f\n\t" \
-        MFSGD_SOLO_CHAIN_HALF("108", "109", "110", "111", "104", "105", "106", "107", "118", "119", "116:117", "32", "24", EXTRA, SFMA) \
+        MFSGD_SOLO_CHAIN_HALF("108", "109", "110", "111", "104", "105", "106", "107", "118", "119", "116:117", "32", "0", "128", "129", EXTRA, SFMA) \
+        "ds_write2_b32 v138, v130, v128 offset0:2 offset1:6\n\t" \
         "v_add_u32 v138, 32, v138\n\t" \
         "s_cbranch_scc0 1b\n\t" \
+        "s_branch 3f\n\t" \
         "2:\n\t" \
-        "s_waitcnt lgkmcnt(0)\n\t"
+        "ds_write_b32 v138, v130 offset:8\n\t" \
+        "3:\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_mov_b32 %[q0], v100\n\t" \
+        "v_mov_b32 %[q1], v101\n\t" \
+        "v_mov_b32 %[q2], v102\n\t" \
+        "v_mov_b32 %[q3], v103\n\t"
 
 #define MFSGD_SOLO_CHAIN_OPERANDS                                                                                      \
-    : [n] "+s"(n)                                                                                                      \
-    : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [c2] "s"(c2), [q0] "v"(q[0]), [q1] "v"(q[1]), [q2] "v"(q[2]),     \
-      [q3] "v"(q[3]), [pad] "n"(PADV)                                                                                  \
+    : [n] "+s"(n), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3])                                  \
+    : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [c2] "s"(c2), [pad] "n"(PADV)                                     \
     : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
-      "v113", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v130", "v131", "v132",  \
-      "v133", "v138", "v139"
+      "v113", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v128", "v129", "v130",  \
+      "v131", "v132", "v133", "v138", "v139"
 
 // ---- helper wave ------------------------------------------------------------------------------
 // v138 entry pointer (-> entry t at the top of half A), v139 row base + lane offset; v[100:103] q_t;
@@ -311,7 +326,8 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "v_add_u32 v138, 32, v138\n\t" \
         "s_cbranch_scc0 5b\n\t" \
         "8:\n\t" \
-        "s_nop 0\n\t" \
+        "s_cmp_eq_u32 %[fin], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
         "ds_write_b128 v140, v[100:103]\n\t" \
         "s_branch 9f\n\t" \
         MFSGD_SOLO_HELPER_SLOW("0", "116", "8") \
@@ -321,7 +337,7 @@ constexpr int mfsgd_pad_helper(int lanes) {
 
 #define MFSGD_SOLO_HELPER_OPERANDS                                                                                     \
     : [n] "+s"(n), [spins] "+s"(spins)                                                                                 \
-    : [ea] "v"(ea), [rb] "v"(rowbase), [c2] "s"(c2), [pad] "n"(PADV)                                                                 \
+    : [ea] "v"(ea), [rb] "v"(rowbase), [c2] "s"(c2), [fin] "s"(fin), [pad] "n"(PADV)                                                                 \
     : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110",  \
       "v111", "v112", "v113", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",  \
       "v129", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140"

@@ -18,6 +18,7 @@
 #define SWAP16 "v_mov_b32 v133, v132\n\ts_nop 1\n\tv_permlane16_swap_b32 v132, v133\n\ts_nop 1\n\tv_add_f32 v132, v132, v133\n\t"
 #define SWAP32 "v_mov_b32 v133, v132\n\ts_nop 1\n\tv_permlane32_swap_b32 v132, v133\n\ts_nop 1\n\tv_add_f32 v132, v132, v133\n\t"
 #define SFMA MFSGD_SFMA_V
+#define SFMA2 MFSGD_SFMA2_V
 #if LG == 16
 #define EXTRA ""
 #elif LG == 32
@@ -29,6 +30,8 @@
 #define EXTRA MFSGD_BCAST_ADD64
 #undef SFMA
 #define SFMA MFSGD_SFMA_S
+#undef SFMA2
+#define SFMA2 MFSGD_SFMA2_S
 #endif
 #endif
 
@@ -39,13 +42,13 @@ constexpr int GS = 64 / LG;                    // slots per step of the (old) ru
 constexpr int RUN_OFF = ENT_OFF + (NSTEP + 2) * 16;  // mode 3: run-loop entries, NSTEP + 2 steps x GS x 16 bytes
 constexpr int EXTRA_ZERO = NROWS;              // (mode 3 idle slots use the zero row too)
 
-__global__ void __launch_bounds__(128) k(const float* rows_in, const uint32_t* ent_in, float* rows_out, uint32_t* ent_out,
+__global__ void __launch_bounds__(192) k(const float* rows_in, const uint32_t* ent_in, float* rows_out, uint32_t* ent_out,
                                          unsigned long long* cyc, int n_steps, float lr, float c, int mode,
                                          const uint32_t* run_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    for (int x = threadIdx.x; x < NROWS * ROWB / 4; x += 128) ((float*)smem)[x] = rows_in[x];
-    for (int x = threadIdx.x; x < (NSTEP + 2) * 4; x += 128) ((uint32_t*)(smem + ENT_OFF))[x] = ent_in[x];
-    for (int x = threadIdx.x; x < (NSTEP + 2) * GS * 4; x += 128) ((uint32_t*)(smem + RUN_OFF))[x] = run_in[x];
+    for (int x = threadIdx.x; x < NROWS * ROWB / 4; x += blockDim.x) ((float*)smem)[x] = rows_in[x];
+    for (int x = threadIdx.x; x < (NSTEP + 2) * 4; x += blockDim.x) ((uint32_t*)(smem + ENT_OFF))[x] = ent_in[x];
+    for (int x = threadIdx.x; x < (NSTEP + 2) * GS * 4; x += blockDim.x) ((uint32_t*)(smem + RUN_OFF))[x] = run_in[x];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned rowbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem + (lane % LG) * 16;
@@ -66,22 +69,52 @@ __global__ void __launch_bounds__(128) k(const float* rows_in, const uint32_t* e
         constexpr int PADV = mfsgd_pad_run(LG);
         asm volatile(MFSGD_RUN_LOOP_ASM_TEXT(EXTRA, SFMA) MFSGD_RUN_LOOP_ASM_OPERANDS);
         if (g == 0) *(f4*)(smem + qaddr) = q;
+    } else if (wave == 0 && mode == 4) {
+        // cut run: the chain wave stores q into its row between the halves (kernels.hip, solo_split)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 q = *(const f4*)(smem + NSTEP * ROWB + (lane % LG) * 16);
+        constexpr int PADV = mfsgd_pad_chain(LG);
+        const int m = (n_steps / 2) & ~1;
+        const unsigned ea0 = ea;
+        n = m;
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
+        *(f4*)(smem + NSTEP * ROWB + (lane % LG) * 16) = q;
+        {
+            const unsigned ea = ea0 + m * 16;
+            n = n_steps - m;
+            asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
+        }
     } else if (wave == 0 && mode != 2) {
         typedef float f4 __attribute__((ext_vector_type(4)));
-        const f4 q = *(const f4*)(smem + NSTEP * ROWB + (lane % LG) * 16);
+        f4 q = *(const f4*)(smem + NSTEP * ROWB + (lane % LG) * 16);
         constexpr int PADV = mfsgd_pad_chain(LG);
-        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA, SFMA) MFSGD_SOLO_CHAIN_OPERANDS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
     } else if (wave == 1 && (mode == 0 || mode == 2)) {
-        int spins = 1 << 20;
+        int spins = 1 << 20, fin = 1;
+        asm volatile("" : "+s"(fin));
         constexpr int PADV = mfsgd_pad_helper(LG);
         asm volatile(MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_OPERANDS);
         if (spins == 0 && lane == 0) cyc[2] = 1;
+    } else if ((wave == 1 || wave == 2) && mode == 4) {
+        // the two helpers of a cut run: wave 1 follows [0, m) and leaves q alone, wave 2 follows [m, n)
+        const int m = (n_steps / 2) & ~1;
+        int spins = 1 << 20, fin = wave == 2;
+        fin = __builtin_amdgcn_readfirstlane(fin);
+        asm volatile("" : "+s"(fin));
+        const unsigned ea0 = ea;
+        {
+            const unsigned ea = wave == 1 ? ea0 : ea0 + m * 16;
+            n = __builtin_amdgcn_readfirstlane(wave == 1 ? m : n_steps - m);
+            constexpr int PADV = mfsgd_pad_helper(LG);
+            asm volatile(MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_OPERANDS);
+        }
+        if (spins == 0 && lane == 0) cyc[2] = 1;
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-    if (lane == 0) cyc[wave] = t1 - t0;
+    if (lane == 0) cyc[wave == 2 ? 3 : wave] = t1 - t0;
     __syncthreads();
-    for (int x = threadIdx.x; x < NROWS * ROWB / 4; x += 128) rows_out[x] = ((float*)smem)[x];
-    for (int x = threadIdx.x; x < (NSTEP + 2) * 4; x += 128) ent_out[x] = ((uint32_t*)(smem + ENT_OFF))[x];
+    for (int x = threadIdx.x; x < NROWS * ROWB / 4; x += blockDim.x) rows_out[x] = ((float*)smem)[x];
+    for (int x = threadIdx.x; x < (NSTEP + 2) * 4; x += blockDim.x) ent_out[x] = ((uint32_t*)(smem + ENT_OFF))[x];
 }
 
 static float ref_dot(const float* p, const float* q) {
@@ -186,17 +219,18 @@ int main() {
     uint32_t* d_run;
     (void)hipMalloc(&d_run, run.size() * 4);
     (void)hipMemcpy(d_run, run.data(), run.size() * 4, hipMemcpyHostToDevice);
-    for (int mode = 0; mode < 4; ++mode)
-        for (int n : {NSTEP, NSTEP - 1, 1, 2}) {
-            if (mode == 3 && (n & 1)) continue;
+    for (int mode = 0; mode < 5; ++mode)
+        for (int n : {NSTEP, NSTEP - 1, 1, 2, 50, 51}) {
+            if ((mode == 3 && (n & 1)) || (mode == 4 && n < 8)) continue;
             (void)hipMemcpy(d_ent, (mode == 2 ? ent2 : ent).data(), ent.size() * 4, hipMemcpyHostToDevice);
             unsigned long long best[2] = {~0ull, ~0ull}, h[4];
             std::vector<float> out(rows.size());
             for (int rep = 0; rep < 5; ++rep) {
                 (void)hipMemset(d_cyc, 0, 32);
-                hipLaunchKernelGGL(k, dim3(1), dim3(128), lds, 0, d_in, d_ent, d_out, d_ent_out, d_cyc, n, lr, c, mode, d_run);
+                hipLaunchKernelGGL(k, dim3(1), dim3(mode == 4 ? 192 : 128), lds, 0, d_in, d_ent, d_out, d_ent_out, d_cyc, n, lr, c, mode, d_run);
                 (void)hipMemcpy(h, d_cyc, 32, hipMemcpyDeviceToHost);
                 if (h[2]) printf("helper gave up!\n");
+                if (mode == 4 && h[3] > h[1]) h[1] = h[3];  // cut run: the later of the two helpers
                 for (int w = 0; w < 2; ++w) best[w] = h[w] < best[w] ? h[w] : best[w];
             }
             (void)hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost);
@@ -217,7 +251,7 @@ int main() {
                 bad = memcmp(out.data(), r2.data(), out.size() * 4) != 0;
             }
             printf("L=%d mode=%d (%s) n=%d: chain %.1f cycles/step, helper %.1f cycles/step%s\n", LG, mode,
-                   mode == 1 ? "chain alone" : mode == 2 ? "helper alone" : mode == 3 ? "one-wave run loop" : "chain + helper", n, (double)best[0] / n, (double)best[1] / n,
+                   mode == 1 ? "chain alone" : mode == 4 ? "cut run: chain + two helpers" : mode == 2 ? "helper alone" : mode == 3 ? "one-wave run loop" : "chain + helper", n, (double)best[0] / n, (double)best[1] / n,
                    mode == 1 ? "" : (bad ? "  MISMATCH" : "  bit-exact"));
         }
     return 0;
