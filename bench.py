@@ -116,7 +116,19 @@ def main():
                     "code path of this file (global plan, ring under the C-ABI, its timing) with PARTS item partitions and an "
                     "RCCL self-ring on this rank alone")
     ap.add_argument("--round-launch", action="store_true", help="one kernel per round instead of the persistent epoch kernel")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="debugging: the N-rank code path of this file with "
+                    "EVERY rank on GPU (local_rank mod device count) -- the ring under the C-ABI moves its blocks through the "
+                    "driver's shared-memory rehearsal transport (RCCL refuses two ranks on one GPU), round launches (the "
+                    "ranks' persistent kernels would not be co-resident).  Not a measurement.")
     args = ap.parse_args()
+    # stdout carries ONE line, the JSON.  Native libraries write there too (gloo announces its peers on stdout):
+    # from here on file descriptor 1 is stderr, and the line goes to a copy of the real stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    if args.rehearse_on_one_gpu:
+        os.environ["MFSGD_DSGD_TRANSPORT"] = "shm"  # read by mfsgd_dsgd_unique_id on rank 0
+        args.round_launch = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,7 +146,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libmfsgd has no CPU path")
-    if args.backend == "gloo":
+    if args.backend == "gloo" or args.rehearse_on_one_gpu:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -354,7 +366,7 @@ def main():
             "blocks": infos[0]["blocks"], "waves": infos[0]["waves"],
             "parts_per_rank": ppr, "emulated_world": emu,
             "parallelism": (f"selftest-1rank-{selftest}parts" if selftest else "single") if world == 1 else f"dsgd{world}" + ("-gloo-rehearsal" if args.backend == "gloo" else "")
-                           + ("-native-rccl-ring" if native else "") + ring_note,
+                           + (("-native-shm-ring-one-gpu-rehearsal" if args.rehearse_on_one_gpu else "-native-rccl-ring") if native else "") + ring_note,
         },
         "rmse_before": rmse0,
         "rmse_after": rmse1,
@@ -382,7 +394,7 @@ def main():
         log("timing the CPU baseline (oracle, multithreaded) ...")
         out["cpu_baseline"] = cpu_baseline(w, m)
     m.close()
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
