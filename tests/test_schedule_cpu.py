@@ -384,3 +384,37 @@ def test_two_items_in_a_tile_are_not_a_lone_tile(mf, oracle):
     lone = (cells[:, 5] & 1).reshape(2, 2)  # [block, tile]
     assert not lone[:, shared[0]].any()
     assert lone[:, 1 - shared[0]].all()  # the other tile IS one item (item 0), rated from both blocks
+
+
+def test_fuzz_dominant_items_replay_exactly(mf, oracle):
+    """Random problems with one to three dominant items (tiles of their own, one sub-cell per cell, solo runs,
+    chunked when k is large): conflict check, the invariants of the marked tiles and the emulator's replay of the
+    device arrays against the oracle's sequential pass (all inside _check)."""
+    rng = np.random.default_rng(9090)
+    lone = 0
+    for _ in range(24):
+        k = int(rng.choice([16, 64, 64, 100, 128, 256]))
+        B = int(rng.integers(2, 9))
+        U = int(rng.integers(20, 60)) * B
+        I = int(rng.integers(12, 60))
+        u, i = [], []
+        for h in rng.choice(I, size=int(rng.integers(1, 4)), replace=False):
+            sel = np.flatnonzero(rng.random(U) < rng.uniform(0.5, 1.0))
+            u += sel.tolist()
+            i += [int(h)] * sel.size
+        m = int(rng.integers(1, 4)) * U
+        u += rng.integers(0, U, m).tolist()
+        i += rng.integers(0, I, m).tolist()
+        key = rng.permutation(np.unique(np.array(u, np.int64) * I + np.array(i, np.int64)))
+        uu, ii = (key // I).astype(np.int32), (key % I).astype(np.int32)
+        rr = (rng.random(key.size) * 4 + 1).astype(np.float32)
+        W = int(rng.choice([1, 2, 2, 4]))
+        try:
+            _check(mf, oracle, U, I, k, uu, ii, rr, blocks=B, waves=W)
+        except mf.MfsgdError as e:
+            assert e.code == -7, e  # an explicit B too small for the LDS image is a legal refusal
+            continue
+        with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 3, blocks=B, waves=W) as m2:
+            m2.set_ratings(uu, ii, rr)
+            lone += int((m2.debug_schedule()[0][:, 5] & 1).any())
+    assert lone >= 2, lone  # (the marked tiles need k >= 64, unchunked cells and an item heavy enough for its B)
