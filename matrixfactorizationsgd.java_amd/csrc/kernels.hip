@@ -77,7 +77,7 @@ __device__ __forceinline__ void solo_chain_asm(float4& rq, const unsigned ea, co
     if constexpr (L == 16)
         asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT("", MFSGD_SFMA2_V) MFSGD_SOLO_CHAIN_OPERANDS);
     else if constexpr (L == 32)
-        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_SWAP_ADD16, MFSGD_SFMA2_V) MFSGD_SOLO_CHAIN_OPERANDS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_BCAST_ADD32, MFSGD_SFMA2_S) MFSGD_SOLO_CHAIN_OPERANDS);
     else
         asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(MFSGD_BCAST_ADD64, MFSGD_SFMA2_S) MFSGD_SOLO_CHAIN_OPERANDS);
     rq = make_float4(q[0], q[1], q[2], q[3]);  // q after the n steps (the helper stores it; the caller needs it when it cuts a run)

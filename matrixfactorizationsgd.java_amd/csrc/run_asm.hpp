@@ -161,6 +161,9 @@ constexpr int mfsgd_pad_helper(int lanes) {
 // bits of the contract's tree, addition being commutative -- and a v_readlane broadcasts it.  Two DPP
 // adds and two moves on the dependent chain instead of two five-instruction swap levels.
 #define MFSGD_BCAST_ADD64 "s_nop 1\n\tv_add_f32_dpp v132, v132, v132 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\tv_add_f32_dpp v132, v132, v132 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0\n\tv_readlane_b32 vcc_lo, v132, 63\n\t"
+// The same idea for the xor-16 level of a SOLO run at L = 32 (one rating per wave there too: both lane groups
+// work on it): row_bcast:15 puts S0+S1 into row 1 (lane 31), a v_readlane hands it on as a scalar.
+#define MFSGD_BCAST_ADD32 "s_nop 1\n\tv_add_f32_dpp v132, v132, v132 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 0\n\tv_readlane_b32 vcc_lo, v132, 31\n\t"
 // s = fma(-lr, dot, lr*r): the dot in v132 (every lane of the group holds it), or -- after
 // MFSGD_BCAST_ADD64 -- in vcc_lo, with lr in v131 (one scalar operand per VALU instruction on gfx9)
 #define MFSGD_SFMA_V(LRR) "v_fma_f32 v130, -%[lr], v132, v" LRR "\n\t"

@@ -23,6 +23,11 @@
 #define EXTRA ""
 #elif LG == 32
 #define EXTRA SWAP16
+#ifndef OLD32
+#define EXTRA_SOLO MFSGD_BCAST_ADD32  // the solo chain: one rating per wave
+#undef SFMA2
+#define SFMA2 MFSGD_SFMA2_S
+#endif
 #else
 #ifdef OLD64
 #define EXTRA SWAP16 SWAP32
@@ -33,6 +38,10 @@
 #undef SFMA2
 #define SFMA2 MFSGD_SFMA2_S
 #endif
+#endif
+
+#ifndef EXTRA_SOLO
+#define EXTRA_SOLO EXTRA
 #endif
 
 constexpr int ROWB = 16 * LG;
@@ -77,18 +86,18 @@ __global__ void __launch_bounds__(192) k(const float* rows_in, const uint32_t* e
         const int m = (n_steps / 2) & ~1;
         const unsigned ea0 = ea;
         n = m;
-        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA_SOLO, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
         *(f4*)(smem + NSTEP * ROWB + (lane % LG) * 16) = q;
         {
             const unsigned ea = ea0 + m * 16;
             n = n_steps - m;
-            asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
+            asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA_SOLO, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
         }
     } else if (wave == 0 && mode != 2) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         f4 q = *(const f4*)(smem + NSTEP * ROWB + (lane % LG) * 16);
         constexpr int PADV = mfsgd_pad_chain(LG);
-        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA_SOLO, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
     } else if (wave == 1 && (mode == 0 || mode == 2)) {
         int spins = 1 << 20, fin = 1;
         asm volatile("" : "+s"(fin));
