@@ -11,3 +11,4 @@ done
 # L = 64 with the two v_permlane*_swap levels instead of the row_bcast reduction (what round 1 ran)
 $HIPCC --offload-arch=gfx950 -O2 -ffp-contract=off -DLG=64 -DOLD64 -Wno-unused-value ubench3.hip -o bin/ub3_64old
 $HIPCC --offload-arch=gfx950 -O2 ubench.hip -o bin/ubench
+$HIPCC --offload-arch=gfx950 -O2 -Wno-unused-value ubench4.hip -o bin/ub4
