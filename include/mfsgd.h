@@ -187,7 +187,8 @@ int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t
 
 /* Diagnostic (not part of the Java surface): the device-facing schedule arrays of a
  * partition, so that tests can replay the kernel's exact LDS access order on the CPU.
- * cells: n_cells x 8 words {row_off, ent_off, n_steps, nu | ni << 16, next chunk, 3 reserved}: chunk
+ * cells: n_cells x 8 words {row_off, ent_off, n_steps, nu | ni << 16, next chunk, flags, 2 reserved} (flags bit 0:
+ * the cell's tile is ONE item row in every cell -- it is handed on through the tile's mailbox): chunk
  * descriptors -- the first blocks*blocks are the first chunk of each cell, a cell too large for
  * the LDS continues through `next` (0 = last chunk) into the descriptors behind them;
  * subs: n_subs x 2 words {off | solo steps << 16, general steps | run steps << 16};
