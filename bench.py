@@ -6,14 +6,24 @@
 A "step" is one epoch: one pass of the hot path (dot, error, rank-1 update of
 P[u] and Q[i]) over every rating of the workload.  N = 1 runs BASELINE.json's
 configs[2] -- the configuration its metric is quoted on: MovieLens-20M shape
-(138,493 x 26,744, 20M ratings), k = 64, fp32 -- on synthetic data.  N > 1 is
-DSGD (weak scaling): every rank holds the same number of users and ratings as
-the N = 1 run and the item catalogue is N times larger (users, items and ratings
-all scale with N); the item factors are cut into N blocks that rotate between
-the ranks over RCCL send/recv; value = ratings processed by all ranks / max-over-
-ranks time.  Ratings, schedules and factors are resident in HBM before the
-timed region; the timed region contains the training passes only (no RMSE
-pass, no host<->device copies).
+(138,493 x 26,744, 20M ratings), k = 64, fp32 -- on synthetic data.
+
+N > 1 is DSGD: one process per GPU, the item factors cut into N (x parts-per-rank)
+blocks that rotate between the ranks over RCCL send/recv under the C-ABI
+(csrc/dsgd.cpp).  `python bench.py --gpus N` starts the N ranks itself (fresh
+child processes, before anything in this process touches the GPU) and relays
+rank 0's JSON line; under `python -m torch.distributed.run` (RANK / WORLD_SIZE in
+the environment) it is one of the ranks.  Two problem definitions:
+
+  --scaling weak    every rank brings the users and ratings of the N = 1 run and
+                    the item catalogue is N times larger (default for cfg2_*);
+  --scaling strong  ONE global rating set (BASELINE configs 3 and 4 as stated: the
+                    Netflix shape and the power-law shape cut over the N GPUs by
+                    mfsgd_dsgd_plan); default for cfg3_netflix / cfg4_powerlaw.
+
+value = ratings processed by all ranks / max-over-ranks time.  Ratings, schedules
+and factors are resident in HBM before the timed region; the timed region
+contains the training passes only (no RMSE pass, no host<->device copies).
 
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" (algorithmic bytes of
 the dominant kernel / its average launch duration vs the 8 TB/s HBM peak) and
@@ -34,6 +44,9 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 LR, LAM, SEED = 0.01, 0.05, 3
+# generator revision of the named workloads (synth.py WORKLOADS): bumped whenever a calibration changes, so that
+# two bench lines of the same workload name are comparable only if this matches (r1: cfg2 head 40 K; r2: 67.9 K)
+WORKLOAD_REV = 2
 
 
 def host_threads():
@@ -48,31 +61,99 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+# ---- N > 1 without a launcher: this process starts the ranks ---------------------------------------------
+def spawn_ranks(n, argv):
+    """Starts `n` fresh copies of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays
+    rank 0's stdout (the one JSON line) and returns the worst exit code.  Nothing here touches the GPU: the children
+    are new processes, not re-executions of one that has initialised HIP."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rk in range(n):
+        env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if rk == 0 else subprocess.DEVNULL))
+    rc, alive = 0, set(range(n))
+    try:
+        while alive:
+            for rk in sorted(alive):
+                r = procs[rk].poll()
+                if r is None:
+                    continue
+                alive.discard(rk)
+                if r != 0 and rc == 0:
+                    rc = r if r > 0 else 1
+                    log(f"rank {rk} exited with {r}; stopping the others")
+                    for other in alive:  # exactly the processes started above
+                        procs[other].terminate()
+            if alive:
+                time.sleep(0.1)
+    except BaseException:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise
+    out = procs[0].stdout.read().decode()
+    if rc == 0:
+        lines = [x for x in out.splitlines() if x.strip()]
+        if len(lines) != 1:
+            log(f"rank 0 printed {len(lines)} lines instead of one")
+            rc = 1
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    return rc
+
+
 def cpu_baseline(w, m, budget_s=12.0):
     """Times the oracle's multithreaded block-schedule epoch (kind "port": this
     repository's CPU restatement; the reference has no runnable CPU path) on the
-    same ratings and the same schedule, for about `budget_s` seconds."""
+    same ratings and the same schedule, for about `budget_s` seconds -- the bit-exact
+    checker's arithmetic (lane-tree dot) first, then the plain left-to-right fp32 loop a
+    Java maintainer would write (`textbook`), same schedule and threads, with the RMSE
+    gap between the two after the same number of epochs."""
     from tests.oracle_bind import Oracle
 
     orc = Oracle()
     info = m.schedule_info()
     order, cell_ptr = m.order()
     threads = host_threads()
-    P, Q = orc.init_factors(w["U"], w["I"], w["k"], SEED)
-    # whole epochs; stop once the budget is used (at least one)
-    t_used, epochs = 0.0, 0
-    while epochs < 1 or (t_used < budget_s and t_used / epochs * (epochs + 1) < budget_s * 1.5):
-        t0 = time.perf_counter()
-        orc.sgd_epoch_mt(P, Q, w["u"], w["i"], w["r"], order, cell_ptr, info["rounds"], info["blocks"], LR, LAM, threads)
-        t_used += time.perf_counter() - t0
-        epochs += 1
+
+    def run(fn, budget):
+        P, Q = orc.init_factors(w["U"], w["I"], w["k"], SEED)
+        t_used, epochs, rm = 0.0, 0, []
+        # whole epochs; stop once the budget is used (at least one)
+        while epochs < 1 or (t_used < budget and t_used / epochs * (epochs + 1) < budget * 1.5):
+            t0 = time.perf_counter()
+            fn(P, Q, w["u"], w["i"], w["r"], order, cell_ptr, info["rounds"], info["blocks"], LR, LAM, threads)
+            t_used += time.perf_counter() - t0
+            epochs += 1
+            if epochs <= 2:  # the RMSE gap between the two arithmetics: two epochs are enough (a single-threaded pass each)
+                rm.append(orc.rmse(P, Q, w["u"], w["i"], w["r"]))
+        return t_used, epochs, rm
+
+    t_c, e_c, rm_c = run(orc.sgd_epoch_mt, budget_s)
+    t_t, e_t, rm_t = run(orc.textbook_epoch_mt, budget_s * 0.75)
+    n = min(len(rm_c), len(rm_t))
     return {
-        "value": w["nnz"] * epochs / t_used,
+        "value": w["nnz"] * e_c / t_c,
         "unit": "updates/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{epochs} full epoch(s) of the same {w['nnz']} ratings and block schedule, "
-                  f"oracle/mfsgd_oracle.c mfo_sgd_epoch_mt, {t_used:.1f} s",
+        "sample": f"{e_c} full epoch(s) of the same {w['nnz']} ratings and block schedule, "
+                  f"oracle/mfsgd_oracle.c mfo_sgd_epoch_mt (the bit-exact checker's arithmetic), {t_c:.1f} s",
+        "textbook": {
+            "value": w["nnz"] * e_t / t_t, "unit": "updates/s", "cores": threads, "kind": "port",
+            "sample": f"{e_t} full epoch(s), mfo_textbook_epoch_mt: plain left-to-right fp32 loop p += lr*(e*q - lambda*p) "
+                      f"on the same block schedule and threads, {t_t:.1f} s",
+            "rmse_gap_to_contract": max(abs(a - b) for a, b in zip(rm_c[:n], rm_t[:n])),
+            "epochs_compared": n,
+        },
     }
 
 
@@ -100,18 +181,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2_ml20m")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="N > 1: weak = every rank brings the N = 1 problem (items x N); strong = one global rating set cut "
+                         "over the ranks by mfsgd_dsgd_plan; auto = strong for cfg3_netflix / cfg4_powerlaw, weak otherwise")
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo "
-                    "(rehearsal: several ranks on one GPU, ring staged through host memory)")
-    ap.add_argument("--ring", default="native", help="native: the ring under the C-ABI (csrc/dsgd.cpp, RCCL send/recv on "
-                    "its own stream; torch.distributed/gloo only hands out the RCCL id and takes the max of the times); "
-                    "torch: the Python harness dsgd.py over torch.distributed P2P")
     ap.add_argument("--parts-per-rank", type=int, default=0, help="DSGD: item partitions a rank holds at a time (0 = 1)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debugging: run ONE rank of an N-GPU DSGD job on one "
                     "GPU without communication (per-rank compute time of that job)")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="which rank --emulate-world runs (strong scaling: its user range)")
     ap.add_argument("--selftest-native-ring", type=int, default=0, metavar="PARTS", help="debugging, one GPU: run the N > 1 "
                     "code path of this file (global plan, ring under the C-ABI, its timing) with PARTS item partitions and an "
                     "RCCL self-ring on this rank alone")
@@ -121,6 +201,11 @@ def main():
                     "driver's shared-memory rehearsal transport (RCCL refuses two ranks on one GPU), round launches (the "
                     "ranks' persistent kernels would not be co-resident).  Not a measurement.")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver calls it: this process is the launcher
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     # stdout carries ONE line, the JSON.  Native libraries write there too (gloo announces its peers on stdout):
     # from here on file descriptor 1 is stderr, and the line goes to a copy of the real stdout.
     sys.stdout.flush()
@@ -135,8 +220,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     emu = args.emulate_world if args.emulate_world > 1 and world == 1 else 0
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
 
     import torch
@@ -146,7 +229,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libmfsgd has no CPU path")
-    if args.backend == "gloo" or args.rehearse_on_one_gpu:
+    if args.rehearse_on_one_gpu:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -154,45 +237,74 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        if args.backend == "gloo" or args.ring == "native":
-            dist.init_process_group("gloo", rank=rank, world_size=world)  # control plane only when the ring is native
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # control plane only (the RCCL id, the item histogram, the max of the times): the blocks travel under the C-ABI
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    # ---- workload (rank-specific users and ratings; items are shared) -----------
-    t0 = time.time()
-    # weak scaling: every rank brings its own 138,493 users and 20 M ratings, and the item
-    # catalogue grows with the rank count (N x 26,744 items), so that the longest per-row
-    # dependency chain a rank has to serialise stays what it is at N = 1
     vworld = emu if emu else world  # ranks the problem is sized for
-    w = synth.workload(args.workload, args.scale, seed_offset=1000 * rank, item_mult=vworld)
-    if rank == 0:
-        log(f"generated {w['nnz']} ratings ({w['U']} x {w['I']}, {w['dist']}) in {time.time() - t0:.1f} s")
-    k, nnz = w["k"], w["nnz"]
-    # the longest chain of dependent updates on one row: what a sequentially consistent epoch cannot go below
-    max_item_degree = int(np.bincount(w["i"], minlength=w["I"]).max())
-    max_user_degree = int(np.bincount(w["u"], minlength=w["U"]).max())
-    flags = (_lib.FLAG_NO_GRAPH if args.no_graph else 0) | (_lib.FLAG_ROUND_LAUNCH if args.round_launch else 0)
+    vrank = (args.emulate_rank % emu) if emu else rank
+    scaling = args.scaling
+    if scaling == "auto":
+        scaling = "strong" if args.workload in ("cfg3_netflix", "cfg4_powerlaw") else "weak"
+    if vworld == 1:
+        scaling = "weak"  # one rank: the two definitions coincide
 
     # partitions of one rank share its users, so they are trained one after another; more than
-    # one per rank only makes the schedules smaller
+    # one per rank only makes the schedules smaller and lets the shifts hide behind training
     ppr = args.parts_per_rank if args.parts_per_rank > 0 else 1
     selftest = args.selftest_native_ring if world == 1 and not emu and args.selftest_native_ring > 1 else 0
     if selftest:
         ppr = selftest
     n_parts = vworld * ppr if (vworld > 1 or selftest) else 0
+    native = world > 1 or bool(selftest)
+
+    # ---- workload --------------------------------------------------------------------------------------------
+    t0 = time.time()
+    u_offset, u_total = 0, None
+    if scaling == "strong":
+        # ONE global rating set; every rank derives the same plan from the same degrees and keeps its user range
+        w = synth.workload(args.workload, args.scale)
+        nnz_global = w["nnz"]
+        deg_u = np.bincount(w["u"], minlength=w["U"]).astype(np.int64)
+        deg_i = np.bincount(w["i"], minlength=w["I"]).astype(np.int64)
+        max_item_degree, max_user_degree = int(deg_i.max()), int(deg_u.max())
+        user_begin, _ = mfsgd_amd.dsgd_plan(deg_u, deg_i, vworld)
+        _, item_part = mfsgd_amd.dsgd_plan(deg_u, deg_i, n_parts)
+        lo, hi = int(user_begin[vrank]), int(user_begin[vrank + 1])
+        sel = np.flatnonzero((w["u"] >= lo) & (w["u"] < hi))
+        u_total, u_offset = w["U"], lo
+        w = dict(w, U=hi - lo, u=(w["u"][sel] - lo).astype(np.int32), i=w["i"][sel], r=w["r"][sel], nnz=int(sel.size),
+                 U_global=u_total)
+        del sel
+    else:
+        # weak scaling: every rank brings its own 138,493 users and 20 M ratings, and the item
+        # catalogue grows with the rank count (N x 26,744 items), so that the longest per-row
+        # dependency chain a rank has to serialise stays what it is at N = 1
+        w = synth.workload(args.workload, args.scale, seed_offset=1000 * vrank, item_mult=vworld)
+        nnz_global = w["nnz"] * vworld
+        u_total, u_offset = w["U"] * vworld, vrank * w["U"]
+        # the longest chain of dependent updates on one row: what a sequentially consistent epoch cannot go below
+        max_item_degree = int(np.bincount(w["i"], minlength=w["I"]).max())
+        max_user_degree = int(np.bincount(w["u"], minlength=w["U"]).max())
+        item_part = None
+        if n_parts:
+            # the global partitioner: item partitions balanced by the GLOBAL rating counts (users are already
+            # dealt out evenly: every rank brought the same number of ratings)
+            deg_i = torch.from_numpy(np.bincount(w["i"], minlength=w["I"]).astype(np.int64))
+            if dist is not None:
+                dist.all_reduce(deg_i)
+            elif emu:
+                deg_i = deg_i * emu  # one rank of the job: the other ranks' histograms look like this one's
+            _, item_part = mfsgd_amd.dsgd_plan(np.ones(vworld, np.int64), deg_i.numpy(), n_parts)
+    if rank == 0:
+        log(f"generated {w['nnz']} ratings ({w['U']} x {w['I']}, {w['dist']}, scaling {scaling}) in {time.time() - t0:.1f} s")
+    k, nnz = w["k"], w["nnz"]
+    flags = (_lib.FLAG_NO_GRAPH if args.no_graph else 0) | (_lib.FLAG_ROUND_LAUNCH if args.round_launch else 0)
+
     m = mfsgd_amd.MatrixFactorizationSGD(w["U"], w["I"], k, LR, LAM, SEED, device=local_rank, blocks=args.blocks,
                                          waves=args.waves, n_parts=n_parts,
                                          host_threads=host_threads(), flags=flags)
     t0 = time.time()
-    native = (world > 1 and args.ring == "native" and args.backend != "gloo") or bool(selftest)
-    if native:
-        # the global partitioner: item partitions balanced by the GLOBAL rating counts (users are already
-        # dealt out evenly: every rank brought the same number of ratings)
-        deg_i = torch.from_numpy(np.bincount(w["i"], minlength=w["I"]).astype(np.int64))
-        if dist is not None:
-            dist.all_reduce(deg_i)
-        _, item_part = mfsgd_amd.dsgd_plan(np.ones(world, np.int64), deg_i.numpy(), n_parts)
+    if item_part is not None:
         m.set_item_partition(item_part)
     m.set_ratings(w["u"], w["i"], w["r"])
     infos = [m.schedule_info(p) for p in range(max(1, n_parts))]
@@ -203,40 +315,11 @@ def main():
 
     launches_per_epoch = sum((i["rounds"] if args.round_launch else 1) for i in infos if i["nnz"] > 0)
 
-    d_native, ring_note = None, ""
-    if native:
-        # the ring under the C-ABI; every rank must take the same path, so they agree on whether it came up
-        from mfsgd_amd.dsgd import NativeDSGD
-
-        why = ""
-        try:
-            obj = [NativeDSGD.unique_id() if rank == 0 else None]
-        except Exception as e:  # noqa: BLE001
-            obj, why = [None], repr(e)
-        if dist is not None:
-            dist.broadcast_object_list(obj, src=0)
-        m.init_p_offset(SEED, rank * w["U"])
-        if obj[0] is not None:
-            try:
-                d_native = NativeDSGD(m, rank, world, obj[0])
-            except Exception as e:  # noqa: BLE001
-                why = repr(e)
-        ok = torch.tensor([1 if d_native is not None else 0], dtype=torch.int32)
-        if dist is not None:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if not bool(ok[0]):
-            if selftest:
-                raise SystemExit(f"--selftest-native-ring: the ring did not come up: {why}")
-            log(f"rank {rank}: the ring under the C-ABI did not come up ({why or 'another rank failed'}); "
-                "using the torch.distributed harness instead (see config.parallelism)")
-            if d_native is not None:
-                d_native.close()
-            d_native, native, ring_note = None, False, "-torch-ring-fallback"
-
     def _barrier():
         if dist is not None:
             dist.barrier()
 
+    ring_stats = None
     if vworld == 1 and not selftest:
         m.init_factors(SEED)
         rmse0 = m.rmse()  # also moves everything to the device
@@ -249,10 +332,17 @@ def main():
         wall_s = time.perf_counter() - t_wall0
         elapsed_s = max(wall_s, dev_ms / 1e3)
         rmse1 = m.rmse()
-        total_updates = nnz * args.steps
-    elif d_native is not None:
-        d = d_native
-        d.init_q(SEED, w["U"] * world)
+    elif native:
+        # the ring under the C-ABI (csrc/dsgd.cpp): RCCL send / recv on its own stream.  It comes up on every rank or the
+        # bench fails -- a line produced by another transport would not measure the product
+        from mfsgd_amd.dsgd import NativeDSGD
+
+        obj = [NativeDSGD.unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(obj, src=0)
+        m.init_p_offset(SEED, u_offset)
+        d = NativeDSGD(m, rank, world, obj[0])
+        d.init_q(SEED, u_total)
         rmse0 = d.rmse()
         d.train(args.warmup, rmse=False)
         torch.cuda.synchronize()
@@ -271,59 +361,50 @@ def main():
         dev_ms = elapsed_s * 1e3
         launches = launches_per_epoch * args.steps
         rmse1 = d.rmse()
-        total_updates = nnz * world * args.steps
+        ring_stats = d.stats()
         d.close()
     else:
+        # --emulate-world: one rank of an `emu`-rank job on this GPU, the ring shift a local copy, every group visited
         from mfsgd_amd.dsgd import DSGD, HipBackend, TorchDistRing
 
-        u_total = w["U"] * vworld
-        m.init_p_offset(SEED, rank * w["U"])
-        # blocks travel over torch.distributed P2P: RCCL ("nccl") unless this is a gloo rehearsal
-        group = None
-        if world > 1 and args.backend != "gloo" and dist.get_backend() != "nccl":
-            group = dist.new_group(backend="nccl")
-        ring = TorchDistRing(dist, rank, world, group=group)
-        if emu:
-            # one rank of an `emu`-rank job: the ring shift is a local copy, every group is visited
-            class _Loop(TorchDistRing):
-                def shift(self, a, b):
-                    b.copy_(a)
-            ring = _Loop(None, 0, 1)
-        d = DSGD(HipBackend(m, dev), ring, rank, vworld, w["I"], m.kp, SEED, u_total, nnz, parts_per_rank=ppr)
-        sse0, n0 = ring.sum_f64([d.sse(), float(nnz)], torch, dev)
-        rmse0 = (sse0 / n0) ** 0.5
+        m.init_p_offset(SEED, u_offset)
+
+        class _Loop(TorchDistRing):
+            def shift(self, a, b):
+                b.copy_(a)
+
+        ring = _Loop(None, 0, 1)
+        d = DSGD(HipBackend(m, dev), ring, vrank, vworld, w["I"], m.kp, SEED, u_total, nnz, parts_per_rank=ppr)
+        rmse0 = (d.sse() / max(1, nnz)) ** 0.5  # this rank's ratings only
         for _ in range(args.warmup):
             d.epoch()
-        torch.cuda.synchronize()
-        ring.barrier()
         torch.cuda.synchronize()
         t_wall0 = time.perf_counter()
         for _ in range(args.steps):
             d.epoch()
         torch.cuda.synchronize()
-        ring.barrier()
-        torch.cuda.synchronize()
         wall_s = time.perf_counter() - t_wall0
-        elapsed_s = ring.max_f64(wall_s, torch, dev)
+        elapsed_s = wall_s
         dev_ms = elapsed_s * 1e3
         launches = launches_per_epoch * args.steps
-        sse1, n1 = ring.sum_f64([d.sse(), float(nnz)], torch, dev)
-        rmse1 = (sse1 / n1) ** 0.5
-        total_updates = nnz * world * args.steps
+        rmse1 = (d.sse() / max(1, nnz)) ** 0.5
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
+        m.close()
         return
 
+    # whole-job updates: all ranks' ratings (an emulated rank reports its own share only)
+    total_updates = (nnz if emu else (nnz_global if world > 1 else nnz)) * args.steps
     value = total_updates / elapsed_s
-    # ---- roofline of the dominant kernel (sgd cell kernel, one launch per round) --
+    # ---- roofline of the dominant kernel ------------------------------------------------------------------------
     # algorithmic bytes per update: 12 (COO triple) + 4 rows x 4k bytes, no reuse credited
     bytes_per_update = 16 * k + 12
-    avg_launch_s = (dev_ms / 1e3) / max(1, launches)  # N > 1: partitions of a group run concurrently
-    units_per_launch = nnz * args.steps / max(1, launches)  # per rank
+    avg_launch_s = (dev_ms / 1e3) / max(1, launches)  # N > 1: one launch per partition and epoch, one after another
+    units_per_launch = nnz * args.steps / max(1, launches)  # this rank's
     achieved_gbs = units_per_launch * bytes_per_update / avg_launch_s / 1e9  # per GPU
-    traffic, traffic_source = read_traffic(args.workload, k, nnz) if world == 1 else (None, None)
+    traffic, traffic_source = read_traffic(args.workload, k, nnz) if (world == 1 and not emu and not selftest) else (None, None)
     roofline = {
         # "hbm" is the roofline this path is priced against (gather + axpy, 0.74 flop/B).  `achieved` is
         # ALGORITHMIC bytes / time, a throughput yardstick: what actually limits a skewed epoch is the longest
@@ -344,6 +425,10 @@ def main():
         "avg_launch_us": avg_launch_s * 1e6,
         "launches": launches,
     }
+    if world == 1:
+        par = f"selftest-1rank-{selftest}parts-native-rccl-self-ring" if selftest else (f"one-rank-of-dsgd{emu}-no-communication" if emu else "single")
+    else:
+        par = f"dsgd{world}" + ("-native-shm-ring-one-gpu-rehearsal" if args.rehearse_on_one_gpu else "-native-rccl-ring")
     out = {
         "metric": "rating-updates/sec",
         "value": value,
@@ -353,20 +438,21 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed_s * 1e3 / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload} (MovieLens-20M shape, Zipf-Mandelbrot degrees)" if args.workload == "cfg2_ml20m" else args.workload,
-            "users_per_gpu": w["U"], "items": w["I"], "nnz_per_gpu": nnz, "k": k,
+            "workload_rev": WORKLOAD_REV,
+            "generator": {x: v for x, v in synth.WORKLOADS[args.workload].items() if x not in ("U", "I", "nnz", "k")},
+            "users_per_gpu": w["U"], "items": w["I"], "nnz_per_gpu": nnz, "nnz_global": nnz_global, "users_global": u_total, "k": k,
             "lr": LR, "lambda": LAM, "scale": args.scale,
             "max_item_degree": max_item_degree, "max_user_degree": max_user_degree,
             "sum_round_steps": sum(i["sum_round_steps"] for i in infos),
             "blocks": infos[0]["blocks"], "waves": infos[0]["waves"],
-            "parts_per_rank": ppr, "emulated_world": emu,
-            "parallelism": (f"selftest-1rank-{selftest}parts" if selftest else "single") if world == 1 else f"dsgd{world}" + ("-gloo-rehearsal" if args.backend == "gloo" else "")
-                           + (("-native-shm-ring-one-gpu-rehearsal" if args.rehearse_on_one_gpu else "-native-rccl-ring") if native else "") + ring_note,
+            "parts_per_rank": ppr, "emulated_world": emu, "emulated_rank": vrank if emu else None,
+            "parallelism": par,
         },
         "rmse_before": rmse0,
         "rmse_after": rmse1,
@@ -374,6 +460,8 @@ def main():
         "wall_ms": wall_s * 1e3,
         "roofline": roofline,
     }
+    if ring_stats is not None:
+        out["ring"] = ring_stats
     if world == 1 and not emu and not selftest:
         # What a caller of train(u, i, r, 10) with HOST arrays sees end to end on a fresh handle: hashing and
         # uploading the triples, building the schedule (device ingest + device packer), seeding the factors,
@@ -390,8 +478,8 @@ def main():
             "value": nnz * 10 / e2e[1], "unit": "updates/s", "epochs": 10, "seconds": e2e[1], "first_call_seconds": e2e[0],
             "includes": "host arrays -> set_ratings (hash, upload, device ingest + packer) -> init_factors -> 10 x (epoch + RMSE pass)",
         }
-    if world == 1 and not args.no_cpu_baseline:
-        log("timing the CPU baseline (oracle, multithreaded) ...")
+    if world == 1 and not emu and not selftest and not args.no_cpu_baseline:
+        log("timing the CPU baselines (oracle, multithreaded: the checker's arithmetic, then the textbook loop) ...")
         out["cpu_baseline"] = cpu_baseline(w, m)
     m.close()
     print(json.dumps(out), file=json_out, flush=True)

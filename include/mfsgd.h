@@ -270,6 +270,12 @@ int mfsgd_part_sse(mfsgd_handle* h, int32_t part, const float* q_block_dev, void
 /* Seeds P when this handle holds users [u_offset, u_offset + n_users) of a
  * larger problem: stream position of P row u is (u_offset + u) * k.           */
 int mfsgd_init_p_offset(mfsgd_handle* h, int64_t seed, int64_t u_offset);
+/* The recovery point of an asynchronous sub-epoch: waits for `stream`; if the LAST mfsgd_part_train of this
+ * partition found its persistent launch not co-resident (another kernel held CUs; the launch then changed
+ * nothing), the sub-epoch is trained now, as one launch per round on the same stream, and waited for;
+ * *rerun (nullable) = 1 then and the partition stays on round launches.  Call it with the same block
+ * BEFORE the block is passed on; csrc/dsgd.cpp does so where an exchange may share the GPU with training. */
+int mfsgd_part_settle(mfsgd_handle* h, int32_t part, float* q_block_dev, void* stream, int32_t* rerun);
 /* Waits for `stream` and reports whether a training launch of this partition gave up on a
  * hand-off since the last check (MFSGD_ERR_HIP then: the factors are invalid).  mfsgd_part_train
  * is asynchronous and cannot report that itself.                                             */
@@ -320,6 +326,10 @@ int mfsgd_dsgd_train_timed(mfsgd_dsgd* d, int32_t epochs, double* elapsed_ms);
 /* All-reduce of two doubles over the ranks (op 0 = sum, 1 = max): what a host needs for global
  * counts and max-over-ranks timings without a second communication library.                  */
 int mfsgd_dsgd_allreduce(mfsgd_dsgd* d, double* values2, int32_t op);
+/* Counters of this rank's ring since mfsgd_dsgd_create: out4 = {sub-epoch trainings enqueued, of those run with
+ * the recovery point (mfsgd_part_settle before the block leaves), of those re-run as round launches because the
+ * persistent launch was not co-resident, bytes sent}.                                                         */
+int mfsgd_dsgd_stats(const mfsgd_dsgd* d, int64_t* out4);
 
 #ifdef __cplusplus
 }

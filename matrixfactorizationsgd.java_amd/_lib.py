@@ -111,6 +111,7 @@ SIGNATURES = {
     "mfsgd_part_sse": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, _f64p]),
     "mfsgd_init_p_offset": (C.c_int, [_H, C.c_int64, C.c_int64]),
     "mfsgd_part_sync": (C.c_int, [_H, C.c_int32, C.c_void_p]),
+    "mfsgd_part_settle": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, _i32p]),
     "mfsgd_get_parts": (C.c_int, [_H, _i32p, _i32p, _i32p]),
     "mfsgd_dsgd_unique_id": (C.c_int, [C.c_void_p]),
     "mfsgd_dsgd_create": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(_H)]),
@@ -123,6 +124,7 @@ SIGNATURES = {
     "mfsgd_dsgd_rmse": (C.c_int, [_H, _f64p]),
     "mfsgd_dsgd_train_timed": (C.c_int, [_H, C.c_int32, _f64p]),
     "mfsgd_dsgd_allreduce": (C.c_int, [_H, _f64p, C.c_int32]),
+    "mfsgd_dsgd_stats": (C.c_int, [_H, _i64p]),
 }
 
 _lib = None

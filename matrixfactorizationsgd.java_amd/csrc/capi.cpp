@@ -375,8 +375,11 @@ int check_abort(mfsgd_handle* h, Part& p, unsigned* started = nullptr) {
 
 // The persistent kernel could not get all its workgroups onto the chip (something else is running
 // there): from now on this partition is trained with one launch per round, which needs no co-residency.
-void give_up_persistence(mfsgd_handle* h, Part& p) {
-    (void)hipDeviceSynchronize();
+// `idle` (nullable): the one stream this partition's launches went to, already synchronised by the caller -- then
+// nothing of the partition is in flight and the device-wide wait (which would also wait for a DSGD ring's exchange
+// with a slower peer on its communication stream) is not needed.
+void give_up_persistence(mfsgd_handle* h, Part& p, const hipStream_t* idle = nullptr) {
+    if (!idle) (void)hipDeviceSynchronize();
     drop_graphs(p);
     p.persistent_np = 0;
     h->n_not_resident++;
@@ -389,7 +392,8 @@ int check_abort_strict(mfsgd_handle* h, Part& p) {
     give_up_persistence(h, p);
     return fail(h, MFSGD_ERR_HIP,
                 "persistent epoch kernel: workgroups not co-resident (another kernel holds the GPU); the launch and those "
-                "queued behind it were NOT applied -- this partition now uses one launch per round, repeat the epoch");
+                "queued behind it of THIS partition were NOT applied -- the partition now uses one launch per round.  If other "
+                "work depended on it (a DSGD ring that passed the block on), the factors are invalid: seed or load them again");
 }
 
 int launch_sse(mfsgd_handle* h, Part& p, const float* Q, hipStream_t st) {
@@ -429,11 +433,16 @@ int settle_epochs(mfsgd_handle* h, Part& p, float* Q, hipStream_t st, int launch
     unsigned started = 0;
     int rc = check_abort(h, p, &started);
     if (rc != kNotResident) return rc;
-    give_up_persistence(h, p);
+    give_up_persistence(h, p, &st);
     for (int e = (int)std::min<unsigned>(started, (unsigned)launched); e < launched; ++e)
         if ((rc = launch_epoch(h, p, Q, st))) return rc;
     HIPCHK(h, hipStreamSynchronize(st));
-    return MFSGD_OK;
+    return kNotResident;  // recovered: the missing epochs ran as round launches
+}
+
+int settle_epochs_ok(mfsgd_handle* h, Part& p, float* Q, hipStream_t st, int launched) {
+    const int rc = settle_epochs(h, p, Q, st, launched);
+    return rc == kNotResident ? MFSGD_OK : rc;
 }
 
 // Host copies of a device-packed schedule's big arrays, made when somebody asks for them
@@ -779,6 +788,9 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
                 }
                 Part& p = h->parts[(size_t)g];
                 p.q_rows = h->part_q_rows[(size_t)g];
+                // uu / ii of two partitions of equal size sit at the same addresses (the allocator hands the block
+                // back): the ingest context must not take them for the arrays it already holds on the device
+                if (ingest.ctx && ingest.forget) ingest.forget(ingest.ctx);
                 prm.I = std::max<int32_t>(1, p.q_rows);
                 prm.validated = true;  // checked above; local rows are in range by construction
                 std::string err;
@@ -922,12 +934,12 @@ int mfsgd_train(mfsgd_handle* h, int32_t epochs, double* rmse_per_epoch) {
         if ((rc = launch_epoch(h, p, Q, h->stream))) return rc;
         if (rmse_per_epoch) {
             double sse = 0.0;
-            if ((rc = settle_epochs(h, p, Q, h->stream, 1))) return rc;
+            if ((rc = settle_epochs_ok(h, p, Q, h->stream, 1))) return rc;
             if ((rc = part_sse_sync(h, p, Q, h->stream, &sse))) return rc;
             rmse_per_epoch[e] = p.sched.nnz > 0 ? std::sqrt(sse / (double)p.sched.nnz) : 0.0;
         }
     }
-    return settle_epochs(h, p, Q, h->stream, rmse_per_epoch ? 0 : epochs);
+    return settle_epochs_ok(h, p, Q, h->stream, rmse_per_epoch ? 0 : epochs);
 }
 
 int mfsgd_train_timed(mfsgd_handle* h, int32_t epochs, double* elapsed_ms, int64_t* launches) {
@@ -1302,6 +1314,25 @@ int mfsgd_part_train(mfsgd_handle* h, int32_t part, float* q_block_dev, void* st
     if (rc) return rc;
     // the caller owns the Q block, so the caller names the stream (NULL = HIP's null stream)
     return launch_epoch(h, h->parts[(size_t)part], q_block_dev, static_cast<hipStream_t>(stream));
+}
+
+int mfsgd_part_settle(mfsgd_handle* h, int32_t part, float* q_block_dev, void* stream, int32_t* rerun) {
+    if (rerun) *rerun = 0;
+    if (!h || !q_block_dev) return fail(h, MFSGD_ERR_INVALID_ARG, "part_settle: null argument");
+    if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "part_settle: bad partition");
+    if (!h->device_ready || !h->have_ratings) return MFSGD_OK;  // nothing can have been launched
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    Part& p = h->parts[(size_t)part];
+    if (p.sched.nnz == 0) {
+        HIPCHK(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        return MFSGD_OK;
+    }
+    const int rc = settle_epochs(h, p, q_block_dev, static_cast<hipStream_t>(stream), 1);
+    if (rc == kNotResident) {
+        if (rerun) *rerun = 1;
+        return MFSGD_OK;
+    }
+    return rc;
 }
 
 int mfsgd_part_sync(mfsgd_handle* h, int32_t part, void* stream) {

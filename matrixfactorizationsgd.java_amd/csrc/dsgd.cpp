@@ -147,6 +147,10 @@ struct mfsgd_dsgd {
     std::vector<hipEvent_t> trained, arrived;  // per slot j
     double* d_red = nullptr;                   // 2 doubles for the RMSE all-reduce
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // counters (mfsgd_dsgd_stats): sub-epoch trainings enqueued, of those with the recovery point, of those re-run
+    // as round launches, bytes sent
+    int64_t n_trained = 0, n_checked = 0, n_rerun = 0, bytes_sent = 0;
+    bool always_check = false;  // MFSGD_DSGD_CHECK=1: the recovery point in every sub-epoch
     std::string err;
 
     float* block(int which, int j) const { return buf[which] + (size_t)j * max_rows * kp; }
@@ -193,6 +197,7 @@ int shift_slot(mfsgd_dsgd* d, int j, bool after_training) {
         if (!spin_until([&] { return tk.load(std::memory_order_acquire) == wr.load(std::memory_order_relaxed); }, 120.0))
             return dfail(d, MFSGD_ERR_HIP, "dsgd (shm transport): rank " + std::to_string((d->rank + d->world - 1) % d->world) + " never took the last block");
         DHIP(d, hipMemcpy(r.slot(d->rank, j), d->block(d->cur, j), count * sizeof(float), hipMemcpyDeviceToHost));
+        d->bytes_sent += (int64_t)(count * sizeof(float));
         wr.store(wr.load(std::memory_order_relaxed) + 1, std::memory_order_release);
         auto& swr = H->written[src][j];
         auto& stk = H->taken[src][j];
@@ -210,6 +215,7 @@ int shift_slot(mfsgd_dsgd* d, int j, bool after_training) {
     DNCCL(d, R.Recv(d->block(d->cur ^ 1, j), count, ncclFloat, (d->rank + 1) % d->world, d->comm, d->wire));
     DNCCL(d, R.GroupEnd());
     DHIP(d, hipEventRecord(d->arrived[(size_t)j], d->wire));
+    d->bytes_sent += (int64_t)(count * sizeof(float));
     return MFSGD_OK;
 }
 
@@ -218,12 +224,31 @@ void rotated(mfsgd_dsgd* d) {
     d->group = (d->group + 1) % d->world;
 }
 
-// One epoch, asynchronous: `world` sub-epochs of train-the-group, pass-it-on.
-int enqueue_epoch(mfsgd_dsgd* d) {
+// One epoch: `world` sub-epochs of train-the-group, pass-it-on.  Asynchronous -- no host synchronisation inside --
+// unless `checked`: then every block passes the recovery point (mfsgd_part_settle) before it leaves.  A persistent
+// training launch that finds its workgroups not co-resident (an exchange of the ring, or a foreign kernel, holds CUs)
+// changes nothing; unnoticed, the untrained block would travel on and the ranks' factors diverge for good.  At the
+// recovery point the host waits for the training, and a launch that gave up is repeated as round launches before the
+// block is sent.  Cost: the launch latencies of one sub-epoch, exposed once per sub-epoch.  When it is on:
+//  - the first epoch of every train call: what a launch meets on this node shows there (the partition then stays on
+//    round launches, so later epochs cannot fail the same way);
+//  - every epoch when a rank holds several partitions (m > 1): slot j's exchange is in flight while slot j + 1 is
+//    trained, for the whole run, and how long a peer keeps an exchange waiting is not this rank's to know;
+//  - every epoch under MFSGD_DSGD_CHECK=1.
+// With m = 1 nothing of the ring runs beside a training launch (train -> shift -> train), so the later epochs go
+// unchecked; a launch that still gives up (a foreign process) surfaces in finish() as "factors invalid".
+int enqueue_epoch(mfsgd_dsgd* d, bool checked) {
     for (int s = 0; s < d->world; ++s) {
         for (int j = 0; j < d->m; ++j) {
             DHIP(d, hipStreamWaitEvent(d->compute, d->arrived[(size_t)j], 0));
             DLIB(d, mfsgd_part_train(d->h, d->part(j), d->block(d->cur, j), d->compute));
+            d->n_trained++;
+            if (checked) {
+                int32_t rerun = 0;
+                DLIB(d, mfsgd_part_settle(d->h, d->part(j), d->block(d->cur, j), d->compute, &rerun));
+                d->n_checked++;
+                d->n_rerun += rerun;
+            }
             DHIP(d, hipEventRecord(d->trained[(size_t)j], d->compute));
             int rc = shift_slot(d, j, true);
             if (rc) return rc;
@@ -359,6 +384,7 @@ int mfsgd_dsgd_create(mfsgd_handle* h, int32_t rank, int32_t world, const void* 
     d->k = k;
     d->device = device;
     d->group = rank;
+    if (const char* c = std::getenv("MFSGD_DSGD_CHECK")) d->always_check = std::atoi(c) != 0;
     for (int p = 0; p < n_parts; ++p) {
         int32_t rows = 0;
         mfsgd_schedule_info info;
@@ -536,7 +562,7 @@ int mfsgd_dsgd_rmse(mfsgd_dsgd* d, double* out) {
 int mfsgd_dsgd_train(mfsgd_dsgd* d, int32_t epochs, double* rmse_per_epoch) {
     if (!d || epochs < 0) return dfail(d, MFSGD_ERR_INVALID_ARG, "dsgd_train: bad argument");
     for (int e = 0; e < epochs; ++e) {
-        int rc = enqueue_epoch(d);
+        int rc = enqueue_epoch(d, e == 0 || d->m > 1 || d->always_check);
         if (rc) return rc;
         if (rmse_per_epoch && (rc = mfsgd_dsgd_rmse(d, &rmse_per_epoch[e]))) return rc;
     }
@@ -549,7 +575,7 @@ int mfsgd_dsgd_train_timed(mfsgd_dsgd* d, int32_t epochs, double* elapsed_ms) {
     if (rc) return rc;
     DHIP(d, hipEventRecord(d->ev0, d->compute));
     for (int e = 0; e < epochs; ++e)
-        if ((rc = enqueue_epoch(d))) return rc;
+        if ((rc = enqueue_epoch(d, e == 0 || d->m > 1 || d->always_check))) return rc;
     // the last blocks arrive on the communication stream: the epoch ends when they are home
     for (int j = 0; j < d->m; ++j) DHIP(d, hipStreamWaitEvent(d->compute, d->arrived[(size_t)j], 0));
     DHIP(d, hipEventRecord(d->ev1, d->compute));
@@ -558,6 +584,15 @@ int mfsgd_dsgd_train_timed(mfsgd_dsgd* d, int32_t epochs, double* elapsed_ms) {
     DHIP(d, hipEventElapsedTime(&ms, d->ev0, d->ev1));
     *elapsed_ms = (double)ms;
     return finish(d);
+}
+
+int mfsgd_dsgd_stats(const mfsgd_dsgd* d, int64_t* out4) {
+    if (!d || !out4) return MFSGD_ERR_INVALID_ARG;
+    out4[0] = d->n_trained;
+    out4[1] = d->n_checked;
+    out4[2] = d->n_rerun;
+    out4[3] = d->bytes_sent;
+    return MFSGD_OK;
 }
 
 int mfsgd_dsgd_allreduce(mfsgd_dsgd* d, double* values2, int32_t op) {

@@ -16,7 +16,10 @@ namespace {
 
 struct Ctx {
     int device = 0;
-    // the triples stay on the device between degrees() and bucket() of the same arrays
+    // the triples stay on the device between degrees() and bucket() of the same arrays.  "The same arrays" is
+    // recognised by (pointer, pointer, length), which holds only WITHIN one build: a caller that builds several
+    // schedules from buffers it frees and allocates again (the partitions of a DSGD handle) gets the same addresses
+    // back from the allocator for different contents and must call DeviceIngest::forget between the builds
     const int32_t* host_u = nullptr;
     const int32_t* host_i = nullptr;
     int64_t n = 0;
@@ -437,6 +440,7 @@ DeviceIngest make_device_ingest(int device) {
     d.ctx = c;
     d.degrees = degrees_cb;
     d.bucket = bucket_cb;
+    d.forget = [](void* vctx) { drop_triples(static_cast<Ctx*>(vctx)); };
     d.ext = &kExt;
     return d;
 }

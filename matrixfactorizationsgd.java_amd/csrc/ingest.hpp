@@ -24,6 +24,10 @@ struct DeviceIngest {
     // input order).  Returns 0 on success.
     int (*bucket)(void* ctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
                   int32_t U, int32_t I, int B, int W, int giants, int64_t* bptr, int64_t* sorted) = nullptr;
+    // Drops the device copy of the triples (and everything derived from it).  The copy is recognised by the host
+    // pointers and the length, so it must be forgotten before another rating set is built from buffers that may
+    // sit at the same addresses.
+    void (*forget)(void* ctx) = nullptr;
     const struct DeviceIngestExt* ext = nullptr;  // the device packer, when available
 };
 

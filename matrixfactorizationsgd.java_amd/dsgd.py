@@ -134,6 +134,13 @@ class NativeDSGD:
         self._check(self._lib.mfsgd_dsgd_rmse(self._d, self._C.byref(out)))
         return out.value
 
+    def stats(self):
+        """Counters of this rank's ring: sub-epoch trainings, of those with the recovery point, re-run as round
+        launches after a failed residency check, bytes sent."""
+        out = np.zeros(4, np.int64)
+        self._check(self._lib.mfsgd_dsgd_stats(self._d, out.ctypes.data_as(self._C.POINTER(self._C.c_int64))))
+        return dict(trained=int(out[0]), checked=int(out[1]), rerun_as_round_launches=int(out[2]), bytes_sent=int(out[3]))
+
     def allreduce(self, a, b, op="sum"):
         C = self._C
         v = np.array([a, b], np.float64)

@@ -158,9 +158,43 @@ void mfo_sgd_pass_ordered(float* P, float* Q, int32_t k, const int32_t* u, const
 }
 
 /* ---------------------------------------------------------------------------
+ * The "textbook" loop: what a Java maintainer's per-rating loop looks like --
+ * a plain left-to-right fp32 dot, e = r - dot, then p += lr*(e*q - lambda*p),
+ * q += lr*(e*p_old - lambda*q), every operation rounded on its own (SURVEY.md 8a
+ * rows a1-a3 read literally, no regrouping, no tree).  It is NOT the contract
+ * the GPU is bit-exact against (that is update_impl above); it exists so that
+ * bench.py can report a CPU baseline that is not slowed down by the lane-tree
+ * dot, next to the RMSE gap between the two arithmetics.
+ * ------------------------------------------------------------------------- */
+static inline __attribute__((always_inline)) void textbook_update(float* p, float* q, int32_t k,
+                                                                  float r, float lr, float lambda) {
+    float dot = 0.0f;
+    for (int f = 0; f < k; ++f) dot += p[f] * q[f];
+    const float e = r - dot;
+    for (int f = 0; f < k; ++f) {
+        const float pf = p[f], qf = q[f];
+        p[f] = pf + lr * (e * qf - lambda * pf);
+        q[f] = qf + lr * (e * pf - lambda * qf);
+    }
+}
+
+MFO_CLONES
+void mfo_textbook_pass_ordered(float* P, float* Q, int32_t k, const int32_t* u, const int32_t* i,
+                               const float* r, const int64_t* order, int64_t n, float lr,
+                               float lambda) {
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t x = order[j];
+        textbook_update(P + (int64_t)u[x] * k, Q + (int64_t)i[x] * k, k, r[x], lr, lambda);
+    }
+}
+
+/* ---------------------------------------------------------------------------
  * Multithreaded block-schedule epoch (the CPU baseline; SURVEY.md 8d "CPU
  * baseline timing").  Static cyclic distribution of a round's cells.
  * ------------------------------------------------------------------------- */
+typedef void (*mfo_pass_fn)(float*, float*, int32_t, const int32_t*, const int32_t*, const float*,
+                            const int64_t*, int64_t, float, float);
+
 typedef struct {
     float *P, *Q;
     int32_t k;
@@ -169,6 +203,7 @@ typedef struct {
     const int64_t *order, *cell_ptr;
     int32_t n_rounds, n_cells, n_threads;
     float lr, lambda;
+    mfo_pass_fn pass;
     pthread_barrier_t* bar;
     /* start gate: 0 = wait, 1 = run, 2 = abort (a thread failed to start) */
     pthread_mutex_t mu;
@@ -193,18 +228,17 @@ static void* mt_worker(void* vp) {
         for (int32_t b = a->tid; b < s->n_cells; b += s->n_threads) {
             const int64_t c = (int64_t)rd * s->n_cells + b;
             const int64_t lo = s->cell_ptr[c], hi = s->cell_ptr[c + 1];
-            mfo_sgd_pass_ordered(s->P, s->Q, s->k, s->u, s->i, s->r, s->order + lo, hi - lo,
-                                 s->lr, s->lambda);
+            s->pass(s->P, s->Q, s->k, s->u, s->i, s->r, s->order + lo, hi - lo, s->lr, s->lambda);
         }
         pthread_barrier_wait(s->bar);
     }
     return NULL;
 }
 
-int mfo_sgd_epoch_mt(float* P, float* Q, int32_t k, const int32_t* u, const int32_t* i,
-                     const float* r, const int64_t* order, const int64_t* cell_ptr,
-                     int32_t n_rounds, int32_t n_cells, float lr, float lambda,
-                     int32_t n_threads) {
+static int epoch_mt(mfo_pass_fn pass, float* P, float* Q, int32_t k, const int32_t* u,
+                    const int32_t* i, const float* r, const int64_t* order,
+                    const int64_t* cell_ptr, int32_t n_rounds, int32_t n_cells, float lr,
+                    float lambda, int32_t n_threads) {
     if (n_threads < 1) n_threads = 1;
     pthread_barrier_t bar;
     if (pthread_barrier_init(&bar, NULL, (unsigned)n_threads) != 0) return -1;
@@ -213,7 +247,7 @@ int mfo_sgd_epoch_mt(float* P, float* Q, int32_t k, const int32_t* u, const int3
     sh.P = P; sh.Q = Q; sh.k = k; sh.u = u; sh.i = i; sh.r = r;
     sh.order = order; sh.cell_ptr = cell_ptr;
     sh.n_rounds = n_rounds; sh.n_cells = n_cells; sh.n_threads = n_threads;
-    sh.lr = lr; sh.lambda = lambda; sh.bar = &bar; sh.go = 0;
+    sh.lr = lr; sh.lambda = lambda; sh.pass = pass; sh.bar = &bar; sh.go = 0;
     pthread_mutex_init(&sh.mu, NULL);
     pthread_cond_init(&sh.cv, NULL);
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
@@ -242,6 +276,22 @@ int mfo_sgd_epoch_mt(float* P, float* Q, int32_t k, const int32_t* u, const int3
     pthread_mutex_destroy(&sh.mu);
     pthread_barrier_destroy(&bar);
     return rc;
+}
+
+int mfo_sgd_epoch_mt(float* P, float* Q, int32_t k, const int32_t* u, const int32_t* i,
+                     const float* r, const int64_t* order, const int64_t* cell_ptr,
+                     int32_t n_rounds, int32_t n_cells, float lr, float lambda,
+                     int32_t n_threads) {
+    return epoch_mt(mfo_sgd_pass_ordered, P, Q, k, u, i, r, order, cell_ptr, n_rounds, n_cells, lr,
+                    lambda, n_threads);
+}
+
+int mfo_textbook_epoch_mt(float* P, float* Q, int32_t k, const int32_t* u, const int32_t* i,
+                          const float* r, const int64_t* order, const int64_t* cell_ptr,
+                          int32_t n_rounds, int32_t n_cells, float lr, float lambda,
+                          int32_t n_threads) {
+    return epoch_mt(mfo_textbook_pass_ordered, P, Q, k, u, i, r, order, cell_ptr, n_rounds,
+                    n_cells, lr, lambda, n_threads);
 }
 
 /* SURVEY.md 8a row a6. */

@@ -75,6 +75,20 @@ int mfo_sgd_epoch_mt(float* P, float* Q, int32_t k,
                      int32_t n_rounds, int32_t n_cells,
                      float lr, float lambda, int32_t n_threads);
 
+/* ---- the textbook loop (second CPU baseline; NOT the bit-exact contract) ------
+ * Plain left-to-right fp32: dot = sum p[f]*q[f]; e = r - dot;
+ * p[f] += lr*(e*q[f] - lambda*p[f]); q[f] += lr*(e*p_old[f] - lambda*q[f]).
+ * Same visiting order / block schedule / threads as the functions above, so the
+ * only difference to the contract is the rounding (RMSE gap ~1e-7).          */
+void mfo_textbook_pass_ordered(float* P, float* Q, int32_t k,
+                               const int32_t* u, const int32_t* i, const float* r,
+                               const int64_t* order, int64_t n, float lr, float lambda);
+int mfo_textbook_epoch_mt(float* P, float* Q, int32_t k,
+                          const int32_t* u, const int32_t* i, const float* r,
+                          const int64_t* order, const int64_t* cell_ptr,
+                          int32_t n_rounds, int32_t n_cells,
+                          float lr, float lambda, int32_t n_threads);
+
 /* ---- a6: RMSE = sqrt(sum (r - dot)^2 / n), fp32 dot, fp64 accumulation ---- */
 double mfo_sse(const float* P, const float* Q, int32_t k,
                const int32_t* u, const int32_t* i, const float* r, int64_t n);

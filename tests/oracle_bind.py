@@ -48,6 +48,8 @@ class Oracle:
         L.mfo_sgd_pass_ordered.argtypes = [_f, _f, C.c_int32, _i, _i, _f, _l, C.c_int64, C.c_float, C.c_float]
         L.mfo_sgd_epoch_mt.argtypes = [_f, _f, C.c_int32, _i, _i, _f, _l, _l, C.c_int32, C.c_int32,
                                        C.c_float, C.c_float, C.c_int32]
+        L.mfo_textbook_pass_ordered.argtypes = L.mfo_sgd_pass_ordered.argtypes
+        L.mfo_textbook_epoch_mt.argtypes = L.mfo_sgd_epoch_mt.argtypes
         L.mfo_sse.restype = C.c_double
         L.mfo_sse.argtypes = [_f, _f, C.c_int32, _i, _i, _f, C.c_int64]
         L.mfo_rmse.restype = C.c_double
@@ -111,6 +113,22 @@ class Oracle:
                                      _lp(cell_ptr), n_rounds, n_cells, lr, lam, threads)
         if rc != 0:
             raise RuntimeError("mfo_sgd_epoch_mt failed")
+
+    def textbook_pass_ordered(self, P, Q, u, i, r, order, lr, lam):
+        """Plain left-to-right fp32 loop (second CPU baseline; not the bit-exact contract)."""
+        u, i, r = self._chk(P, Q, u, i, r)
+        order = np.ascontiguousarray(order, np.int64)
+        self.L.mfo_textbook_pass_ordered(_fp(P), _fp(Q), P.shape[1], _ip(u), _ip(i), _fp(r), _lp(order),
+                                         order.size, lr, lam)
+
+    def textbook_epoch_mt(self, P, Q, u, i, r, order, cell_ptr, n_rounds, n_cells, lr, lam, threads):
+        u, i, r = self._chk(P, Q, u, i, r)
+        order = np.ascontiguousarray(order, np.int64)
+        cell_ptr = np.ascontiguousarray(cell_ptr, np.int64)
+        rc = self.L.mfo_textbook_epoch_mt(_fp(P), _fp(Q), P.shape[1], _ip(u), _ip(i), _fp(r), _lp(order),
+                                          _lp(cell_ptr), n_rounds, n_cells, lr, lam, threads)
+        if rc != 0:
+            raise RuntimeError("mfo_textbook_epoch_mt failed")
 
     def sse(self, P, Q, u, i, r):
         u, i, r = self._chk(P, Q, u, i, r)

@@ -452,6 +452,24 @@ def test_device_packer_partitioned_handles(mf):
     assert _same_schedule(mf, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"], n_parts=3)
 
 
+@pytest.mark.parametrize("n_parts", [2, 4])
+def test_equal_sized_partitions_do_not_share_a_stale_device_copy(mf, n_parts):
+    """Partitions of EQUAL size (a dense set cut by i % n_parts): the per-partition (u, i) buffers of
+    mfsgd_set_ratings come back from the allocator at the same addresses, and the ingest context used to take
+    them for the triples it already held on the device -- every partition after the first was bucketed from the
+    previous partition's (u, i) with its own ratings.  Each partition, device-built, against the host-built
+    schedule word for word (advisor finding, round 2; fixed by DeviceIngest::forget between the builds)."""
+    U, I, k = 240, 200, 64
+    u = np.repeat(np.arange(U), I).astype(np.int32)
+    i = np.tile(np.arange(I), U).astype(np.int32)
+    rng = np.random.default_rng(n_parts)
+    perm = rng.permutation(u.size)
+    u, i = u[perm], i[perm]
+    r = (rng.random(u.size) * 4 + 1).astype(np.float32)
+    assert len({int(np.sum(i % n_parts == p)) for p in range(n_parts)}) == 1  # equal partitions
+    _same_schedule(mf, U, I, k, u, i, r, n_parts=n_parts)
+
+
 def test_train_twice_and_new_ratings(mf, oracle):
     w = mf.synth.workload("cfg1_ml100k", scale=0.2)
     with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], LR, LAM, 8) as m:
@@ -774,6 +792,47 @@ def test_native_dsgd_world1_self_ring(mf, oracle, m, k):
     assert np.array_equal(P1, Po)
 
 
+def test_native_dsgd_recovers_when_a_persistent_launch_is_not_resident(mf, oracle):
+    """The ring's recovery point (csrc/dsgd.cpp enqueue_epoch, mfsgd_part_settle): a foreign kernel holds the LDS of
+    all but four CUs while the ring trains, so the persistent launches of its partitions find their workgroups not
+    co-resident and change nothing.  The driver notices BEFORE the block is passed on, trains the sub-epoch as round
+    launches and carries on: factors and Q blocks bit-exact against the sequential definition, the RMSE trajectory
+    too, at least one sub-epoch re-run, and no 'factors invalid'."""
+    from mfsgd_amd.dsgd import NativeDSGD, assemble_q
+
+    rng = np.random.default_rng(321)
+    U, I, k, n, epochs, n_parts = 2000, 1500, 64, 120000, 3, 2
+    key = rng.choice(U * I, n, replace=False)
+    u, i, r = (key // I).astype(np.int32), (key % I).astype(np.int32), (rng.random(n) * 4 + 1).astype(np.float32)
+    with mf.MatrixFactorizationSGD(U, I, k, LR, LAM, 5, n_parts=n_parts, blocks=64, waves=2) as t:
+        t.set_ratings(u, i, r)
+        t.init_p_offset(5, 0)
+        with NativeDSGD(t, 0, 1, NativeDSGD.unique_id()) as d:
+            d.init_q(5, U)
+            first = d.train(1)  # a normal epoch first: persistent launches
+            c0 = t.debug_counters()
+            assert c0["persistent_parts"] == n_parts and c0["not_resident"] == 0, c0
+            assert d.stats()["rerun_as_round_launches"] == 0
+            t.debug_occupy(600)  # 0.6 s: longer than the residency check waits
+            rm = d.train(epochs)
+            st = d.stats()
+            blocks = d.home_blocks()
+            P1, _ = t.get_factors()
+        c1 = t.debug_counters()
+        orders = [t.order(p)[0] for p in range(n_parts)]
+    assert st["rerun_as_round_launches"] >= 1 and st["checked"] == st["trained"], st
+    assert c1["not_resident"] == st["rerun_as_round_launches"] and c1["persistent_parts"] < n_parts, (c1, st)
+    Po, Qo = oracle.init_factors(U, I, k, 5)
+    ref = []
+    for _ in range(epochs + 1):
+        for p in range(n_parts):
+            oracle.sgd_pass_ordered(Po, Qo, u, i, r, orders[p], LR, LAM)
+        ref.append(oracle.rmse(Po, Qo, u, i, r))
+    assert np.array_equal(P1, Po), "P after the recovered epochs differs from the sequential definition"
+    assert np.array_equal(assemble_q(blocks, I, k, n_parts), Qo)
+    np.testing.assert_allclose(np.concatenate([first, rm]), ref, rtol=1e-9)
+
+
 @pytest.mark.parametrize("k,B", [(64, 16), (64, 40), (128, 16), (256, 24), (100, 12)])
 def test_lone_tile_mailbox_hand_off(mf, oracle, monkeypatch, k, B):
     """An item with a tile of its own travels from workgroup to workgroup through the tile's mailbox ({value, tag}
@@ -983,3 +1042,48 @@ def test_compiled_cpp_host_example(mf, oracle):
     assert len(got) == 5
     np.testing.assert_allclose(got, rmo, atol=1e-6)  # printed with six decimals
     assert abs(pred - oracle.predict(Po, Qo, np.array([3], np.int32), np.array([4], np.int32))[0]) <= 1e-6
+
+
+# ---- bench.py as the driver calls it ---------------------------------------------------------------------
+@pytest.mark.parametrize("args,scaling", [(["--gpus", "2"], "weak"), (["--gpus", "3", "--workload", "cfg3_netflix"], "strong"),
+                                          (["--gpus", "2", "--parts-per-rank", "2", "--scaling", "strong"], "strong")])
+def test_bench_launches_its_own_ranks(args, scaling):
+    """`python bench.py --gpus N` -- no torch.distributed.run in front -- starts its N ranks itself and prints ONE JSON
+    line with n_gpus == N from the ring under the C-ABI.  On this one-GPU box the ranks share the GPU
+    (--rehearse-on-one-gpu: the driver's shared-memory transport, round launches; not a measurement), everything else is
+    the code path of the 8-GPU run: launcher, global plan, id broadcast, ring, timing, the line on stdout."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from tests.conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1",
+                        "--scale", "0.01"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [x for x in p.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    n = int(args[1])
+    assert out["n_gpus"] == n and out["steps"] == 2 and out["scaling"] == scaling
+    assert out["config"]["parallelism"] == f"dsgd{n}-native-shm-ring-one-gpu-rehearsal"
+    assert out["value"] > 0 and out["rmse_after"] < out["rmse_before"]
+    assert out["ring"]["trained"] >= 3 * n * out["config"]["parts_per_rank"] and out["ring"]["bytes_sent"] > 0
+    if scaling == "strong":
+        assert out["config"]["nnz_global"] > out["config"]["nnz_per_gpu"]
+
+
+def test_bench_fails_loudly_when_a_rank_fails():
+    """A rank that cannot start (here: a workload name that does not exist) makes the launcher exit non-zero without a JSON line."""
+    import os
+    import subprocess
+    import sys
+
+    from tests.conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--workload", "no_such"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode != 0 and p.stdout.strip() == ""

@@ -192,3 +192,30 @@ def test_order_matters_more_than_arithmetic(oracle, mf):
             oracle.sgd_pass_ordered(P2, Q2, w["u"], w["i"], w["r"], order, 0.01, 0.05)
             gap = max(gap, abs(oracle.rmse(P1, Q1, w["u"], w["i"], w["r"]) - oracle.rmse(P2, Q2, w["u"], w["i"], w["r"])))
         assert 1e-5 < gap < 2e-2, (name, gap)
+
+
+def test_textbook_fp32_loop_tracks_the_contract_within_1e5(oracle, mf):
+    """The second CPU baseline bench.py reports (oracle/mfsgd_oracle.c mfo_textbook_*: a plain left-to-right
+    fp32 loop, p += lr*(e*q - lambda*p), no tree, no regrouping) on the same order and seeds: its RMSE
+    trajectory stays within BASELINE.json's 1e-5 of the contract's (the gap is rounding only), its
+    multithreaded block-schedule form equals its sequential form bit for bit, and it is NOT the contract
+    (the factors differ in the last bits)."""
+    for name, scale, epochs in (("cfg1_ml100k", 1.0, 5), ("cfg2_ml20m", 0.01, 5), ("cfg3_netflix", 0.004, 3)):
+        w = mf.synth.workload(name, scale)
+        with mf.MatrixFactorizationSGD(w["U"], w["I"], w["k"], 0.01, 0.05, 4) as m:
+            m.set_ratings(w["u"], w["i"], w["r"])
+            order, cell_ptr = m.order()
+            info = m.schedule_info()
+        P, Q = oracle.init_factors(w["U"], w["I"], w["k"], 4)
+        Pt, Qt = P.copy(), Q.copy()
+        Pm, Qm = P.copy(), Q.copy()
+        gap = 0.0
+        for _ in range(epochs):
+            oracle.sgd_pass_ordered(P, Q, w["u"], w["i"], w["r"], order, 0.01, 0.05)
+            oracle.textbook_pass_ordered(Pt, Qt, w["u"], w["i"], w["r"], order, 0.01, 0.05)
+            oracle.textbook_epoch_mt(Pm, Qm, w["u"], w["i"], w["r"], order, cell_ptr, info["rounds"], info["blocks"], 0.01, 0.05, 4)
+            gap = max(gap, abs(oracle.rmse(P, Q, w["u"], w["i"], w["r"]) - oracle.rmse(Pt, Qt, w["u"], w["i"], w["r"])))
+        assert gap < 1e-5, (name, gap)
+        np.testing.assert_array_equal(Pt, Pm)
+        np.testing.assert_array_equal(Qt, Qm)
+        assert not np.array_equal(P, Pt)
