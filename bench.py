@@ -259,7 +259,7 @@ def main():
 
     # ---- workload --------------------------------------------------------------------------------------------
     t0 = time.time()
-    u_offset, u_total = 0, None
+    u_offset, u_total, plan_info = 0, None, None
     if scaling == "strong":
         # ONE global rating set; every rank derives the same plan from the same degrees and keeps its user range
         w = synth.workload(args.workload, args.scale)
@@ -267,8 +267,7 @@ def main():
         deg_u = np.bincount(w["u"], minlength=w["U"]).astype(np.int64)
         deg_i = np.bincount(w["i"], minlength=w["I"]).astype(np.int64)
         max_item_degree, max_user_degree = int(deg_i.max()), int(deg_u.max())
-        user_begin, _ = mfsgd_amd.dsgd_plan(deg_u, deg_i, vworld)
-        _, item_part = mfsgd_amd.dsgd_plan(deg_u, deg_i, n_parts)
+        user_begin, item_part, plan_info = mfsgd_amd.dsgd_plan_ex(deg_u, deg_i, vworld, ppr, w["k"])
         lo, hi = int(user_begin[vrank]), int(user_begin[vrank + 1])
         sel = np.flatnonzero((w["u"] >= lo) & (w["u"] < hi))
         u_total, u_offset = w["U"], lo
@@ -294,7 +293,7 @@ def main():
                 dist.all_reduce(deg_i)
             elif emu:
                 deg_i = deg_i * emu  # one rank of the job: the other ranks' histograms look like this one's
-            _, item_part = mfsgd_amd.dsgd_plan(np.ones(vworld, np.int64), deg_i.numpy(), n_parts)
+            _, item_part, plan_info = mfsgd_amd.dsgd_plan_ex(np.ones(vworld, np.int64), deg_i.numpy(), vworld, ppr, w["k"])
     if rank == 0:
         log(f"generated {w['nnz']} ratings ({w['U']} x {w['I']}, {w['dist']}, scaling {scaling}) in {time.time() - t0:.1f} s")
     k, nnz = w["k"], w["nnz"]
@@ -453,6 +452,9 @@ def main():
             "blocks": infos[0]["blocks"], "waves": infos[0]["waves"],
             "parts_per_rank": ppr, "emulated_world": emu, "emulated_rank": vrank if emu else None,
             "parallelism": par,
+            # the global plan: sum over the partitions of their heaviest item's (global) rating count -- what a rank's
+            # epoch serialises, times 1 / world --, chain-critical items, partitions they were packed into, threshold
+            "plan": plan_info,
         },
         "rmse_before": rmse0,
         "rmse_after": rmse1,

@@ -793,6 +793,16 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
                 if (ingest.ctx && ingest.forget) ingest.forget(ingest.ctx);
                 prm.I = std::max<int32_t>(1, p.q_rows);
                 prm.validated = true;  // checked above; local rows are in range by construction
+                // the partition's own rating counts per row: build_schedule_auto compares the longest chain with the
+                // partition's work when it picks the wave count (a chain-bound partition runs on two waves, a
+                // work-bound one on four), exactly as for a single-partition handle
+                std::vector<int64_t> du((size_t)h->cfg.n_users, 0), di((size_t)prm.I, 0);
+                for (int64_t x = 0; x < m; ++x) {
+                    du[(size_t)uu[(size_t)x]]++;
+                    di[(size_t)ii[(size_t)x]]++;
+                }
+                prm.degu = du.data();
+                prm.degi = di.data();
                 std::string err;
                 if (build_schedule_auto(prm, uu.data(), ii.data(), rr.data(), orig.data() + lo, m, p.sched, err) != 0)
                     return fail(h, MFSGD_ERR_SCHEDULE, "partition " + std::to_string(g) + ": " + err);
@@ -1239,6 +1249,24 @@ int mfsgd_dsgd_plan(const int64_t* deg_user, const int64_t* deg_item, int32_t n_
         if (deg_item[x] < 0) return MFSGD_ERR_INVALID_ARG;
     try {
         dsgd_plan(deg_user, deg_item, n_users, n_items, n_parts, user_begin, item_part);
+    } catch (const std::bad_alloc&) {
+        return MFSGD_ERR_OOM;
+    }
+    return MFSGD_OK;
+}
+
+int mfsgd_dsgd_plan_ex(const int64_t* deg_user, const int64_t* deg_item, int32_t n_users, int32_t n_items, int32_t world,
+                       int32_t parts_per_rank, int32_t k, int32_t* user_begin, int32_t* item_part, int64_t* info4) {
+    if (!deg_user || !deg_item || !user_begin || !item_part || n_users < 1 || n_items < 1 || world < 1 || parts_per_rank < 1 ||
+        k < 1 || k > MFSGD_MAX_K || (int64_t)world * parts_per_rank > INT32_MAX)
+        return MFSGD_ERR_INVALID_ARG;
+    for (int32_t x = 0; x < n_users; ++x)
+        if (deg_user[x] < 0) return MFSGD_ERR_INVALID_ARG;
+    for (int32_t x = 0; x < n_items; ++x)
+        if (deg_item[x] < 0) return MFSGD_ERR_INVALID_ARG;
+    try {
+        dsgd_plan_users(deg_user, n_users, world, user_begin);
+        dsgd_plan_items(deg_item, n_items, world * parts_per_rank, world, k, item_part, info4);
     } catch (const std::bad_alloc&) {
         return MFSGD_ERR_OOM;
     }

@@ -1358,48 +1358,133 @@ int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, con
     }
 }
 
-void dsgd_plan(const int64_t* degu, const int64_t* degi, int32_t U, int32_t I, int32_t G, int32_t* user_begin,
-               int32_t* item_part) {
+void dsgd_plan_users(const int64_t* degu, int32_t U, int32_t G, int32_t* user_begin) {
     // users: boundary g is the first user at which the running rating count reaches g/G of the
     // total, pushed right where needed so that no range is empty while users remain
     int64_t total = 0;
     for (int32_t x = 0; x < U; ++x) total += degu[x];
     user_begin[0] = 0;
-    {
-        int64_t acc = 0;
-        int32_t x = 0;
-        for (int32_t g = 1; g < G; ++g) {
-            const int64_t want = (int64_t)(((__int128)total * g + G - 1) / G);
-            while (x < U && acc < want) acc += degu[x++];
-            int32_t b = x;
-            if (b <= user_begin[g - 1]) b = std::min<int32_t>(U, user_begin[g - 1] + 1);
-            if (b > U - (G - g)) b = std::max<int32_t>(user_begin[g - 1], U - (G - g));  // leave one user each for the rest
-            while (x < b) acc += degu[x++];
-            user_begin[g] = b;
-        }
-        user_begin[G] = U;
+    int64_t acc = 0;
+    int32_t x = 0;
+    for (int32_t g = 1; g < G; ++g) {
+        const int64_t want = (int64_t)(((__int128)total * g + G - 1) / G);
+        while (x < U && acc < want) acc += degu[x++];
+        int32_t b = x;
+        if (b <= user_begin[g - 1]) b = std::min<int32_t>(U, user_begin[g - 1] + 1);
+        if (b > U - (G - g)) b = std::max<int32_t>(user_begin[g - 1], U - (G - g));  // leave one user each for the rest
+        while (x < b) acc += degu[x++];
+        user_begin[g] = b;
     }
-    // items: LPT by rating count; unrated items go to the partitions with the fewest rows
-    std::vector<int64_t> deg(degi, degi + I);
-    std::vector<int32_t> bin;
-    lpt_assign(deg, G, bin);
-    std::vector<int64_t> rows((size_t)G, 0);
+    user_begin[G] = U;
+}
+
+// Items -> G partitions, balanced by rating count AND chain-aware.
+//
+// A DSGD sub-epoch cannot end before the heaviest item of its partition has seen all of the rank's ratings of it,
+// one dependent update after the other; a rank's epoch is therefore at least the SUM over the partitions of their
+// heaviest items' chains.  Plain LPT deals the G heaviest items out one per partition -- the worst case for that
+// sum (measured, round 2: 87 K dependent steps per rank at N = 8 on the bench workload against 67.9 K on one
+// device).  Items of ONE partition, on the other hand, advance concurrently (each in its own tile of the
+// partition's block schedule), so heavy items cost nothing extra when they share a partition.  Hence:
+//   1. items in descending order of rating count; an item is CHAIN-CRITICAL when its chain on one rank
+//      (count / world dependent steps of ~(170 + 2L) cycles) is a sizeable fraction (`crit`, default 0.3) of what
+//      the rank's sub-epoch takes when it is bound by work (the scheduler's own model: c_r cycles per rating per
+//      workgroup, c_0 cycles per round, at the block count that minimises their sum);
+//   2. while chain-critical items remain, the next partition is filled SEQUENTIALLY from the sorted list up to an
+//      equal share of what is left (so the critical items sit in as few partitions as the balance allows, heaviest
+//      together), and closed;
+//   3. the rest is dealt over the remaining partitions longest-processing-time-first, as before;
+//   4. items nobody rated go to the partitions with the fewest rows.
+// Balance: every partition is within one item's count of an equal share of what was left when it was opened.
+// info (nullable, 4 values): {sum over partitions of their heaviest item's count, chain-critical items,
+// partitions filled sequentially, the criticality threshold (global count)}.
+void dsgd_plan_items(const int64_t* degi, int32_t I, int32_t G, int32_t world, int32_t k, int32_t* item_part, int64_t* info) {
+    if (world < 1) world = 1;
+    std::vector<int32_t> idx;
+    idx.reserve((size_t)I);
+    int64_t total = 0;
     for (int32_t x = 0; x < I; ++x)
-        if (deg[(size_t)x] > 0) rows[(size_t)bin[(size_t)x]]++;
-    using Item = std::pair<int64_t, int32_t>;
-    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
-    for (int32_t g = 0; g < G; ++g) heap.push({rows[(size_t)g], g});
-    for (int32_t x = 0; x < I; ++x) {
-        if (deg[(size_t)x] > 0) {
-            item_part[x] = bin[(size_t)x];
-            continue;
+        if (degi[x] > 0) {
+            idx.push_back(x);
+            total += degi[x];
         }
-        Item t = heap.top();
-        heap.pop();
-        item_part[x] = t.second;
-        t.first++;
-        heap.push(t);
+    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return degi[a] > degi[b]; });
+    // 1. the threshold
+    const Geometry geo = geometry_for_k(k > 0 ? k : 64);
+    double crit = 0.3;
+    if (const char* e = std::getenv("MFSGD_PLAN_CRIT")) crit = std::atof(e);  // A/B measurements; <= 0: plain LPT
+    int64_t thr = INT64_MAX;
+    if (crit > 0 && G > 1 && total > 0) {
+        const double n_rp = (double)total / G / world;  // ratings of one rank's sub-epoch
+        const double c_r = 48.0 * 4.0 / geo.G, c_0 = 12000.0, c_s = 170.0 + 2.0 * geo.L;
+        const double b = std::min(256.0, std::max(8.0, std::sqrt(n_rp * c_r / c_0)));
+        const double t_rest = n_rp * c_r / b + c_0 * b;
+        thr = std::max<int64_t>(1, (int64_t)(crit * t_rest / c_s * world));
     }
+    int64_t n_crit = 0;
+    while (n_crit < (int64_t)idx.size() && degi[idx[(size_t)n_crit]] >= thr) ++n_crit;
+    // 2. sequential fill while critical items remain
+    std::vector<int64_t> load((size_t)G, 0), heaviest((size_t)G, 0);
+    size_t pos = 0;
+    int32_t p = 0;
+    int64_t left = total;
+    while ((int64_t)pos < n_crit && p < G - 1) {
+        const int64_t cap = (left + (G - p) - 1) / (G - p);
+        while (pos < idx.size() && (load[(size_t)p] == 0 || load[(size_t)p] + degi[idx[pos]] <= cap)) {
+            const int32_t x = idx[pos++];
+            item_part[x] = p;
+            load[(size_t)p] += degi[x];
+            heaviest[(size_t)p] = std::max(heaviest[(size_t)p], degi[x]);
+        }
+        left -= load[(size_t)p];
+        ++p;
+    }
+    const int32_t n_seq = p;
+    // 3. LPT over the partitions still open
+    {
+        using Item = std::pair<int64_t, int32_t>;  // (load, partition): smallest load, then smallest index
+        std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
+        for (int32_t g = p; g < G; ++g) heap.push({0, g});
+        for (; pos < idx.size(); ++pos) {
+            const int32_t x = idx[pos];
+            Item t = heap.top();
+            heap.pop();
+            item_part[x] = t.second;
+            t.first += degi[x];
+            load[(size_t)t.second] = t.first;
+            heaviest[(size_t)t.second] = std::max(heaviest[(size_t)t.second], degi[x]);
+            heap.push(t);
+        }
+    }
+    // 4. unrated items even out the row counts
+    std::vector<int64_t> rows((size_t)G, 0);
+    for (int32_t x : idx) rows[(size_t)item_part[x]]++;
+    {
+        using Item = std::pair<int64_t, int32_t>;
+        std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
+        for (int32_t g = 0; g < G; ++g) heap.push({rows[(size_t)g], g});
+        for (int32_t x = 0; x < I; ++x) {
+            if (degi[x] > 0) continue;
+            Item t = heap.top();
+            heap.pop();
+            item_part[x] = t.second;
+            t.first++;
+            heap.push(t);
+        }
+    }
+    if (info) {
+        info[0] = 0;
+        for (int32_t g = 0; g < G; ++g) info[0] += heaviest[(size_t)g];
+        info[1] = n_crit;
+        info[2] = n_seq;
+        info[3] = thr == INT64_MAX ? 0 : thr;
+    }
+}
+
+void dsgd_plan(const int64_t* degu, const int64_t* degi, int32_t U, int32_t I, int32_t G, int32_t* user_begin,
+               int32_t* item_part) {
+    dsgd_plan_users(degu, U, G, user_begin);
+    dsgd_plan_items(degi, I, G, G, 64, item_part, nullptr);
 }
 
 }  // namespace mfsgd

@@ -182,5 +182,11 @@ int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, con
 // user_begin: G + 1 entries; item_part: I entries in [0, G).
 void dsgd_plan(const int64_t* degu, const int64_t* degi, int32_t U, int32_t I, int32_t G, int32_t* user_begin,
                int32_t* item_part);
+// The two halves (schedule.cpp): users over `G` ranks; items over `G` partitions of a job of `world` ranks at rank
+// k -- balanced by rating count and chain-aware (the chain-critical items packed into as few partitions as the
+// balance allows).  info (nullable): {sum of the partitions' heaviest items, critical items, partitions filled
+// sequentially, threshold}.
+void dsgd_plan_users(const int64_t* degu, int32_t U, int32_t G, int32_t* user_begin);
+void dsgd_plan_items(const int64_t* degi, int32_t I, int32_t G, int32_t world, int32_t k, int32_t* item_part, int64_t* info);
 
 }  // namespace mfsgd

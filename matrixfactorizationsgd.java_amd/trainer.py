@@ -48,6 +48,23 @@ def dsgd_plan(deg_user, deg_item, n_parts):
     return ub, ip
 
 
+def dsgd_plan_ex(deg_user, deg_item, world, parts_per_rank=1, k=64):
+    """mfsgd_dsgd_plan_ex: (user_begin[world + 1], item_part[n_items] over world * parts_per_rank partitions, info) --
+    chain-aware; info = dict(sum_max_chain, critical_items, sequential_parts, threshold)."""
+    du = np.ascontiguousarray(deg_user, np.int64)
+    di = np.ascontiguousarray(deg_item, np.int64)
+    ub = np.empty(int(world) + 1, np.int32)
+    ip = np.empty(di.size, np.int32)
+    info = np.zeros(4, np.int64)
+    rc = _lib.load_library().mfsgd_dsgd_plan_ex(_p(du, C.c_int64), _p(di, C.c_int64), du.size, di.size, int(world),
+                                                int(parts_per_rank), int(k), _p(ub, C.c_int32), _p(ip, C.c_int32),
+                                                _p(info, C.c_int64))
+    if rc != 0:
+        raise MfsgdError(rc, "mfsgd_dsgd_plan_ex: bad argument")
+    return ub, ip, dict(sum_max_chain=int(info[0]), critical_items=int(info[1]), sequential_parts=int(info[2]),
+                        threshold=int(info[3]))
+
+
 class MatrixFactorizationSGD:
     def __init__(self, users, items, k, lr, lam, seed, *, device=0, blocks=0, waves=0,
                  n_parts=0, host_threads=0, flags=0):

@@ -15,18 +15,23 @@ typedef float jfloat;
 typedef double jdouble;
 typedef jint jsize;
 typedef unsigned char jboolean;
+typedef signed char jbyte;
 class _jobject {};
 class _jclass : public _jobject {};
 class _jarray : public _jobject {};
 class _jintArray : public _jarray {};
 class _jfloatArray : public _jarray {};
 class _jdoubleArray : public _jarray {};
+class _jbyteArray : public _jarray {};
+class _jlongArray : public _jarray {};
 typedef _jobject* jobject;
 typedef _jclass* jclass;
 typedef _jarray* jarray;
 typedef _jintArray* jintArray;
 typedef _jfloatArray* jfloatArray;
 typedef _jdoubleArray* jdoubleArray;
+typedef _jbyteArray* jbyteArray;
+typedef _jlongArray* jlongArray;
 #define JNIEXPORT __attribute__((visibility("default")))
 #define JNICALL
 #define JNI_ABORT 2
@@ -42,5 +47,9 @@ struct JNIEnv {
     void SetIntArrayRegion(jintArray a, jsize start, jsize len, const jint* buf);
     void SetFloatArrayRegion(jfloatArray a, jsize start, jsize len, const jfloat* buf);
     void SetDoubleArrayRegion(jdoubleArray a, jsize start, jsize len, const jdouble* buf);
+    jbyteArray NewByteArray(jsize len);
+    void GetByteArrayRegion(jbyteArray a, jsize start, jsize len, jbyte* buf);
+    void SetByteArrayRegion(jbyteArray a, jsize start, jsize len, const jbyte* buf);
+    void GetLongArrayRegion(jlongArray a, jsize start, jsize len, jlong* buf);
 };
 #endif

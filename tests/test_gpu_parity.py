@@ -1042,6 +1042,20 @@ def test_compiled_cpp_host_example(mf, oracle):
     assert len(got) == 5
     np.testing.assert_allclose(got, rmo, atol=1e-6)  # printed with six decimals
     assert abs(pred - oracle.predict(Po, Qo, np.array([3], np.int32), np.array([4], np.int32))[0]) <= 1e-6
+    # the distributed surface of the same host (trainDistributed: world = 1, RCCL self-ring, two item partitions):
+    # its RMSE lines against the sequential definition -- partition 0 then partition 1, each in its exported order
+    dgot = [float(x) for x in re.findall(r"dsgd epoch \d+ rmse ([0-9.]+)", p.stdout)]
+    assert len(dgot) == 3 and re.search(r"dsgd blocks 2 \(partitions 0 1\) trained 6 bytes_sent [1-9]", p.stdout), p.stdout
+    with mf.MatrixFactorizationSGD(U, I, k, 0.01, 0.05, 42, n_parts=2) as m:
+        m.set_ratings(u, i, r)
+        orders = [m.order(part)[0] for part in range(2)]
+    Po, Qo = oracle.init_factors(U, I, k, 42)
+    ref = []
+    for _ in range(3):
+        for part in range(2):
+            oracle.sgd_pass_ordered(Po, Qo, u, i, r, orders[part], 0.01, 0.05)
+        ref.append(oracle.rmse(Po, Qo, u, i, r))
+    np.testing.assert_allclose(dgot, ref, atol=1e-6)
 
 
 # ---- bench.py as the driver calls it ---------------------------------------------------------------------
