@@ -184,11 +184,17 @@ def main():
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="N > 1: weak = every rank brings the N = 1 problem (items x N); strong = one global rating set cut "
                          "over the ranks by mfsgd_dsgd_plan; auto = strong for cfg3_netflix / cfg4_powerlaw, weak otherwise")
+    ap.add_argument("--generator", default="auto", choices=["auto", "host", "device"], help="where the synthetic ratings are made: host "
+                    "(numpy; the sample every committed number of cfg0..cfg3 is quoted on), device (torch on the GPU: the same "
+                    "distribution, another sample, seconds instead of half an hour at 1 B ratings); auto = device for cfg4_powerlaw "
+                    "above 100 M ratings, host otherwise")
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--parts-per-rank", type=int, default=0, help="DSGD: item partitions a rank holds at a time (0 = 1)")
+    ap.add_argument("--plan-crit", type=float, default=0.0, help="DSGD item plan: 0 = longest-processing-time-first (default), "
+                    "> 0 = chain-aware packing with this criticality threshold (mfsgd_dsgd_plan_ex; not for a ring, DESIGN.md section 6)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debugging: run ONE rank of an N-GPU DSGD job on one "
                     "GPU without communication (per-rank compute time of that job)")
     ap.add_argument("--emulate-rank", type=int, default=0, help="which rank --emulate-world runs (strong scaling: its user range)")
@@ -240,6 +246,10 @@ def main():
         # control plane only (the RCCL id, the item histogram, the max of the times): the blocks travel under the C-ABI
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    generator = args.generator
+    if generator == "auto":
+        big = args.workload == "cfg4_powerlaw" and synth.WORKLOADS[args.workload]["nnz"] * args.scale > 100e6
+        generator = "device" if big else "host"
     vworld = emu if emu else world  # ranks the problem is sized for
     vrank = (args.emulate_rank % emu) if emu else rank
     scaling = args.scaling
@@ -261,24 +271,27 @@ def main():
     t0 = time.time()
     u_offset, u_total, plan_info = 0, None, None
     if scaling == "strong":
-        # ONE global rating set; every rank derives the same plan from the same degrees and keeps its user range
-        w = synth.workload(args.workload, args.scale)
-        nnz_global = w["nnz"]
-        deg_u = np.bincount(w["u"], minlength=w["U"]).astype(np.int64)
-        deg_i = np.bincount(w["i"], minlength=w["I"]).astype(np.int64)
-        max_item_degree, max_user_degree = int(deg_i.max()), int(deg_u.max())
-        user_begin, item_part, plan_info = mfsgd_amd.dsgd_plan_ex(deg_u, deg_i, vworld, ppr, w["k"])
-        lo, hi = int(user_begin[vrank]), int(user_begin[vrank + 1])
-        sel = np.flatnonzero((w["u"] >= lo) & (w["u"] < hi))
+        # ONE global rating set; every rank derives the same plan from the same degrees and keeps its user range.  With
+        # the device generator the global set exists only on each rank's GPU while it is being made (1 B ratings for
+        # cfg4_powerlaw: seconds there, half an hour on a host) and only the rank's shard comes down to the host arrays.
+        plan = {}
+
+        def shard(deg_u, deg_i):
+            ub, ip, pinfo = mfsgd_amd.dsgd_plan_ex(deg_u, deg_i, vworld, ppr, synth.WORKLOADS[args.workload]["k"], args.plan_crit)
+            plan.update(ub=ub, ip=ip, info=pinfo, nnz=int(deg_i.sum()), mi=int(deg_i.max()), mu=int(deg_u.max()))
+            return int(ub[vrank]), int(ub[vrank + 1])
+
+        w = synth.workload(args.workload, args.scale, generator=generator, user_range=shard, log=log if rank == 0 else None)
+        nnz_global, max_item_degree, max_user_degree = plan["nnz"], plan["mi"], plan["mu"]
+        item_part, plan_info = plan["ip"], plan["info"]
+        lo, hi = int(plan["ub"][vrank]), int(plan["ub"][vrank + 1])
         u_total, u_offset = w["U"], lo
-        w = dict(w, U=hi - lo, u=(w["u"][sel] - lo).astype(np.int32), i=w["i"][sel], r=w["r"][sel], nnz=int(sel.size),
-                 U_global=u_total)
-        del sel
+        w = dict(w, U=hi - lo, u=(w["u"] - lo).astype(np.int32), U_global=u_total)
     else:
         # weak scaling: every rank brings its own 138,493 users and 20 M ratings, and the item
         # catalogue grows with the rank count (N x 26,744 items), so that the longest per-row
         # dependency chain a rank has to serialise stays what it is at N = 1
-        w = synth.workload(args.workload, args.scale, seed_offset=1000 * vrank, item_mult=vworld)
+        w = synth.workload(args.workload, args.scale, seed_offset=1000 * vrank, item_mult=vworld, generator=generator)
         nnz_global = w["nnz"] * vworld
         u_total, u_offset = w["U"] * vworld, vrank * w["U"]
         # the longest chain of dependent updates on one row: what a sequentially consistent epoch cannot go below
@@ -293,7 +306,7 @@ def main():
                 dist.all_reduce(deg_i)
             elif emu:
                 deg_i = deg_i * emu  # one rank of the job: the other ranks' histograms look like this one's
-            _, item_part, plan_info = mfsgd_amd.dsgd_plan_ex(np.ones(vworld, np.int64), deg_i.numpy(), vworld, ppr, w["k"])
+            _, item_part, plan_info = mfsgd_amd.dsgd_plan_ex(np.ones(vworld, np.int64), deg_i.numpy(), vworld, ppr, w["k"], args.plan_crit)
     if rank == 0:
         log(f"generated {w['nnz']} ratings ({w['U']} x {w['I']}, {w['dist']}, scaling {scaling}) in {time.time() - t0:.1f} s")
     k, nnz = w["k"], w["nnz"]
@@ -318,7 +331,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    ring_stats = None
+    ring_stats = emulation = None
     if vworld == 1 and not selftest:
         m.init_factors(SEED)
         rmse0 = m.rmse()  # also moves everything to the device
@@ -363,30 +376,43 @@ def main():
         ring_stats = d.stats()
         d.close()
     else:
-        # --emulate-world: one rank of an `emu`-rank job on this GPU, the ring shift a local copy, every group visited
-        from mfsgd_amd.dsgd import DSGD, HipBackend, TorchDistRing
-
+        # --emulate-world: ONE rank of an `emu`-rank job on this GPU, no communication.  Every item partition of the rank
+        # is timed on its own (HIP events round `steps` launches on the stream they are launched on).  Two figures come
+        # out of it: the SUM over the partitions -- what this rank computes per epoch -- and emu x the SLOWEST partition:
+        # the ring's pace.  A Q block is trained by one rank after the other, so block p needs emu x t_p per epoch however
+        # the ranks overlap, and with one block per rank every sub-epoch lasts as long as its slowest partition.  The
+        # line reports the ring's pace (`value`, ms_per_step); the sum is in "emulation".
         m.init_p_offset(SEED, u_offset)
-
-        class _Loop(TorchDistRing):
-            def shift(self, a, b):
-                b.copy_(a)
-
-        ring = _Loop(None, 0, 1)
-        d = DSGD(HipBackend(m, dev), ring, vrank, vworld, w["I"], m.kp, SEED, u_total, nnz, parts_per_rank=ppr)
-        rmse0 = (d.sse() / max(1, nnz)) ** 0.5  # this rank's ratings only
-        for _ in range(args.warmup):
-            d.epoch()
-        torch.cuda.synchronize()
-        t_wall0 = time.perf_counter()
-        for _ in range(args.steps):
-            d.epoch()
-        torch.cuda.synchronize()
-        wall_s = time.perf_counter() - t_wall0
-        elapsed_s = wall_s
+        stream = torch.cuda.current_stream(dev)
+        part_ms = []
+        sse0 = sse1 = 0.0
+        for p in range(n_parts):
+            blk = torch.from_numpy(m.part_init_q(p, SEED, u_total)).to(dev)
+            if infos[p]["nnz"] == 0:
+                part_ms.append(0.0)
+                continue
+            sse0 += m.part_sse(p, blk.data_ptr(), stream.cuda_stream)
+            for _ in range(args.warmup):
+                m.part_train(p, blk.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(args.steps):
+                m.part_train(p, blk.data_ptr(), stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            part_ms.append(e0.elapsed_time(e1) / args.steps)
+            sse1 += m.part_sse(p, blk.data_ptr(), stream.cuda_stream)
+            del blk
+        rmse0, rmse1 = (sse0 / max(1, nnz)) ** 0.5, (sse1 / max(1, nnz)) ** 0.5  # this rank's ratings only (partitions trained apart)
+        group_ms = [sum(part_ms[g * ppr:(g + 1) * ppr]) for g in range(vworld)]  # a rank holds a group of ppr partitions at a time
+        ring_ms = vworld * max(group_ms)
+        emulation = {"partition_ms": part_ms, "sum_ms": sum(part_ms), "slowest_group_ms": max(group_ms), "ring_pace_ms": ring_ms,
+                     "note": "ring_pace_ms = world x the slowest group of partitions: what an epoch takes when every block has to be "
+                             "trained by one rank after the other (no communication time included); sum_ms = this rank's own compute"}
+        wall_s = elapsed_s = ring_ms * args.steps / 1e3
         dev_ms = elapsed_s * 1e3
         launches = launches_per_epoch * args.steps
-        rmse1 = (d.sse() / max(1, nnz)) ** 0.5
 
     if rank != 0:
         if dist is not None:
@@ -400,7 +426,8 @@ def main():
     # ---- roofline of the dominant kernel ------------------------------------------------------------------------
     # algorithmic bytes per update: 12 (COO triple) + 4 rows x 4k bytes, no reuse credited
     bytes_per_update = 16 * k + 12
-    avg_launch_s = (dev_ms / 1e3) / max(1, launches)  # N > 1: one launch per partition and epoch, one after another
+    # N > 1: one launch per partition and epoch, one after another (an emulated rank: its own launches, not the ring's pace)
+    avg_launch_s = ((emulation["sum_ms"] * args.steps if emulation else dev_ms) / 1e3) / max(1, launches)
     units_per_launch = nnz * args.steps / max(1, launches)  # this rank's
     achieved_gbs = units_per_launch * bytes_per_update / avg_launch_s / 1e9  # per GPU
     traffic, traffic_source = read_traffic(args.workload, k, nnz) if (world == 1 and not emu and not selftest) else (None, None)
@@ -444,7 +471,7 @@ def main():
         "config": {
             "workload": f"{args.workload} (MovieLens-20M shape, Zipf-Mandelbrot degrees)" if args.workload == "cfg2_ml20m" else args.workload,
             "workload_rev": WORKLOAD_REV,
-            "generator": {x: v for x, v in synth.WORKLOADS[args.workload].items() if x not in ("U", "I", "nnz", "k")},
+            "generator": dict({x: v for x, v in synth.WORKLOADS[args.workload].items() if x not in ("U", "I", "nnz", "k")}, made_on=generator),
             "users_per_gpu": w["U"], "items": w["I"], "nnz_per_gpu": nnz, "nnz_global": nnz_global, "users_global": u_total, "k": k,
             "lr": LR, "lambda": LAM, "scale": args.scale,
             "max_item_degree": max_item_degree, "max_user_degree": max_user_degree,
@@ -464,6 +491,8 @@ def main():
     }
     if ring_stats is not None:
         out["ring"] = ring_stats
+    if emulation is not None:
+        out["emulation"] = emulation
     if world == 1 and not emu and not selftest:
         # What a caller of train(u, i, r, 10) with HOST arrays sees end to end on a fresh handle: hashing and
         # uploading the triples, building the schedule (device ingest + device packer), seeding the factors,

@@ -235,24 +235,28 @@ int mfsgd_debug_round_stamps(mfsgd_handle* h, int32_t part, int32_t round, uint6
  * The global partitioner (host, no GPU): ONE rating set over n_users x n_items is cut for
  * n_parts devices -- users into n_parts contiguous ranges balanced by rating count (device g
  * holds the P rows of users [user_begin[g], user_begin[g+1]) and those users' ratings), items
- * into n_parts partitions balanced by rating count (chain-aware, see mfsgd_dsgd_plan_ex below; items nobody
+ * into n_parts partitions balanced by rating count (longest-processing-time-first; items nobody
  * rated are dealt out to even the row counts).  A pure function of the two degree arrays, so
  * every rank computes the same plan from the same degrees (a rank that only sees its own ratings
  * all-reduces the item histogram first).  user_begin: n_parts + 1 entries; item_part: n_items.  */
 int mfsgd_dsgd_plan(const int64_t* deg_user, const int64_t* deg_item, int32_t n_users, int32_t n_items,
                     int32_t n_parts, int32_t* user_begin, int32_t* item_part);
-/* The same for a job of `world` ranks holding `parts_per_rank` item partitions at a time, at rank k, and
- * CHAIN-AWARE: a rank's epoch is at least the sum over the partitions of their heaviest items' chains of
- * dependent updates, so the chain-critical items (those whose chain on one rank is a sizeable fraction of a
- * work-bound sub-epoch) are packed -- heaviest together, sequentially -- into as few partitions as the rating-count
- * balance allows, and the rest is dealt longest-processing-time-first over the others.  user_begin: world + 1
- * entries; item_part: n_items entries in [0, world * parts_per_rank); info4 (nullable): {sum over the partitions of
- * their heaviest item's rating count, chain-critical items, partitions filled sequentially, the threshold}.
- * mfsgd_dsgd_plan(.., n_parts, ..) is this with world = n_parts, parts_per_rank = 1, k = 64.
- * Java: MatrixFactorizationSGD.plan(degUser, degItem, nParts).                                              */
+/* The same for a job of `world` ranks holding `parts_per_rank` item partitions at a time, at rank k: user_begin has
+ * world + 1 entries, item_part n_items entries in [0, world * parts_per_rank).
+ * chain_crit = 0: items dealt longest-processing-time-first by rating count -- the heaviest items end up one per
+ * partition, the partitions take the same time, and the ring's epoch (world x the slowest partition: a Q block is
+ * trained by one rank after the other) is as short as the heaviest item's own chain allows.  This is what
+ * mfsgd_dsgd_plan does and what a ring of GPUs wants.
+ * chain_crit > 0 (e.g. 0.3): CHAIN-AWARE -- the chain-critical items (those whose chain of dependent updates on one
+ * rank reaches chain_crit of a work-bound sub-epoch) are packed, heaviest together, into as few partitions as the
+ * rating-count balance allows, the rest dealt LPT over the others.  That minimises the SUM over the partitions of
+ * their heaviest items' chains -- what ONE device pays when it runs the partitions back to back (virtual devices) --
+ * at the price of unequal partition times (measured: DESIGN.md section 6); not for a ring.
+ * info4 (nullable): {sum over the partitions of their heaviest item's rating count, chain-critical items,
+ * partitions filled sequentially, the threshold}.   Java: MatrixFactorizationSGD.plan(degUser, degItem, nParts). */
 int mfsgd_dsgd_plan_ex(const int64_t* deg_user, const int64_t* deg_item, int32_t n_users, int32_t n_items,
-                       int32_t world, int32_t parts_per_rank, int32_t k, int32_t* user_begin, int32_t* item_part,
-                       int64_t* info4);
+                       int32_t world, int32_t parts_per_rank, int32_t k, float chain_crit, int32_t* user_begin,
+                       int32_t* item_part, int64_t* info4);
 /* Installs an item -> partition map (n_items entries in [0, n_parts)) on a handle with
  * n_parts > 1, before mfsgd_set_ratings; item i is then row (number of smaller item ids in the
  * same partition) of that partition's Q block.  NULL restores the default below.            */

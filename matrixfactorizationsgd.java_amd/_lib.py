@@ -103,7 +103,7 @@ SIGNATURES = {
     "mfsgd_debug_occupy": (C.c_int, [_H, C.c_int32]),
     "mfsgd_debug_round_stamps": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     "mfsgd_dsgd_plan": (C.c_int, [_i64p, _i64p, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p]),
-    "mfsgd_dsgd_plan_ex": (C.c_int, [_i64p, _i64p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _i64p]),
+    "mfsgd_dsgd_plan_ex": (C.c_int, [_i64p, _i64p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _i32p, _i32p, _i64p]),
     "mfsgd_set_item_partition": (C.c_int, [_H, _i32p]),
     "mfsgd_get_item_partition": (C.c_int, [_H, _i32p, _i32p]),
     "mfsgd_part_rows": (C.c_int, [_H, C.c_int32, _i32p]),

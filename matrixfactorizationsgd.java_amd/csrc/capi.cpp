@@ -360,12 +360,13 @@ int check_abort(mfsgd_handle* h, Part& p, unsigned* started = nullptr) {
     HIPCHK(h, hipMemcpy(w, abort_word(p), sizeof w, hipMemcpyDeviceToHost));
     if (started) *started = w[1];
     if (w[0] != 0 || w[1] != 0) {
-        // the device is idle on this stream (the caller has synchronised); a give-up also leaves arrivals behind
-        const unsigned zeros[6] = {0, 0, 0, 0, 0, 0};
-        if (w[0] != 0)
-            (void)hipMemcpy(abort_word(p) - 4, zeros, sizeof zeros, hipMemcpyHostToDevice);
-        else
-            (void)hipMemcpy(abort_word(p), zeros, 2 * sizeof(unsigned), hipMemcpyHostToDevice);
+        // the device is idle on this stream (the caller has synchronised).  A give-up also leaves arrivals (and the
+        // "somebody left" bit) in the start barrier's counter: zero it.  The GENERATION word next to it is never reset:
+        // the tile mailboxes are tagged with it, and a launch that reused a generation could take a granule an aborted
+        // launch left behind for this launch's (advisor finding, round 2).
+        const unsigned zeros[2] = {0, 0};
+        if (w[0] != 0) (void)hipMemcpy(abort_word(p) - 4, zeros, sizeof(unsigned), hipMemcpyHostToDevice);
+        (void)hipMemcpy(abort_word(p), zeros, 2 * sizeof(unsigned), hipMemcpyHostToDevice);
     }
     if (w[0] == 2u) return kNotResident;
     if (w[0] != 0)
@@ -1256,9 +1257,10 @@ int mfsgd_dsgd_plan(const int64_t* deg_user, const int64_t* deg_item, int32_t n_
 }
 
 int mfsgd_dsgd_plan_ex(const int64_t* deg_user, const int64_t* deg_item, int32_t n_users, int32_t n_items, int32_t world,
-                       int32_t parts_per_rank, int32_t k, int32_t* user_begin, int32_t* item_part, int64_t* info4) {
+                       int32_t parts_per_rank, int32_t k, float chain_crit, int32_t* user_begin, int32_t* item_part,
+                       int64_t* info4) {
     if (!deg_user || !deg_item || !user_begin || !item_part || n_users < 1 || n_items < 1 || world < 1 || parts_per_rank < 1 ||
-        k < 1 || k > MFSGD_MAX_K || (int64_t)world * parts_per_rank > INT32_MAX)
+        k < 1 || k > MFSGD_MAX_K || (int64_t)world * parts_per_rank > INT32_MAX || !(chain_crit >= 0.f))
         return MFSGD_ERR_INVALID_ARG;
     for (int32_t x = 0; x < n_users; ++x)
         if (deg_user[x] < 0) return MFSGD_ERR_INVALID_ARG;
@@ -1266,7 +1268,7 @@ int mfsgd_dsgd_plan_ex(const int64_t* deg_user, const int64_t* deg_item, int32_t
         if (deg_item[x] < 0) return MFSGD_ERR_INVALID_ARG;
     try {
         dsgd_plan_users(deg_user, n_users, world, user_begin);
-        dsgd_plan_items(deg_item, n_items, world * parts_per_rank, world, k, item_part, info4);
+        dsgd_plan_items(deg_item, n_items, world * parts_per_rank, world, k, (double)chain_crit, item_part, info4);
     } catch (const std::bad_alloc&) {
         return MFSGD_ERR_OOM;
     }

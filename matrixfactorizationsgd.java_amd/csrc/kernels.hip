@@ -63,6 +63,21 @@ __device__ __forceinline__ void run_loop_asm(float4& rq, const unsigned ea, cons
     rq = make_float4(q[0], q[1], q[2], q[3]);
 }
 
+// ---- general steps (run_asm.hpp, MFSGD_GEN_LOOP_ASM_TEXT) ---------------------------------
+// `ea`: LDS byte address of this lane group's entry of step 0 (stride EST), n >= 1 steps, c2 = {c, c}.
+template <int EST, int L>
+__device__ __forceinline__ void gen_loop_asm(const unsigned ea, const unsigned rowbase, int n, const float lr, const uint64_t c2) {
+    static_assert(L == 16 || L == 32 || L == 64, "hand-scheduled general loop: 16, 32 or 64 lanes per rating");
+    n = __builtin_amdgcn_readfirstlane(n);
+    constexpr int PADV = mfsgd_pad_gen(L);
+    if constexpr (L == 16)
+        asm volatile(MFSGD_GEN_LOOP_ASM_TEXT("", MFSGD_SFMA_V) MFSGD_GEN_LOOP_ASM_OPERANDS);
+    else if constexpr (L == 32)
+        asm volatile(MFSGD_GEN_LOOP_ASM_TEXT(MFSGD_SWAP_ADD16, MFSGD_SFMA_V) MFSGD_GEN_LOOP_ASM_OPERANDS);
+    else
+        asm volatile(MFSGD_GEN_LOOP_ASM_TEXT(MFSGD_BCAST_ADD64, MFSGD_SFMA_S) MFSGD_GEN_LOOP_ASM_OPERANDS);
+}
+
 // ---- solo run: chain wave / helper wave (run_asm.hpp) -------------------------------------
 // `ea`: LDS byte address of the run's header record, `rowbase`: LDS byte address of row slot 0 plus
 // this lane's 16-byte offset inside a row, n >= 1 steps, c2 = {c, c} as one 64-bit scalar.
@@ -95,6 +110,14 @@ __device__ __forceinline__ bool solo_helper_asm(const unsigned ea, const unsigne
     asm volatile(MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_OPERANDS);
     return spins != 0;
 }
+
+// -DMFSGD_GEN_STEP_CPP: the compiler-scheduled general step everywhere (A/B measurements; it stays the reference form
+// of the step and is what k <= 32 and the RMSE pass run)
+#ifdef MFSGD_GEN_STEP_CPP
+constexpr bool kGenStepCpp = true;
+#else
+constexpr bool kGenStepCpp = false;
+#endif
 
 // copy waves of the persistent training kernel: as many again as apply waves, up to 8 waves in all
 // (16 waves would leave each only 128 VGPRs; the assembly run loop uses v100..v143)
@@ -411,7 +434,13 @@ struct Cell {
             const uint4* ebase = lent + (size_t)(offs & 0xFFFF) * G + g;
             unsigned long long tm0 = 0, tm1 = 0, tm2 = 0;
             if constexpr (TIMED) tm0 = __builtin_amdgcn_s_memtime();
-            if (n > 0) {
+            if (TRAIN && (L == 16 || L == 32 || L == 64) && n > 0 && !kGenStepCpp) {
+                // hand-scheduled form of the loop below (k in 33..256)
+                if constexpr (L == 16 || L == 32 || L == 64) {
+                    const uint64_t c2 = ((uint64_t)__builtin_bit_cast(unsigned, c) << 32) | __builtin_bit_cast(unsigned, c);
+                    gen_loop_asm<G * 16, L>((unsigned)(uintptr_t)(lptr_t)ebase, (unsigned)(uintptr_t)(lptr_t)lr_ + lo, n, lr, c2);
+                }
+            } else if (n > 0) {
                 const uint4* eptr = ebase;
                 StepRegs A, B;
                 A.en = eptr[0];
@@ -610,9 +639,12 @@ cell_kernel(float* __restrict__ P, float* __restrict__ Q, const CellDesc* __rest
 // workgroups inside the GPU, the same shape as the DSGD ring between GPUs.
 //   producer: q rows stored write-through (sc1) -> every wave s_waitcnt vmcnt(0) ->
 //             workgroup barrier -> one lane stores done[b] = R + 1 (relaxed, agent scope);
-//   consumer: one lane polls done[b + 1] >= R (relaxed, agent scope, s_sleep) -> agent
-//             acquire fence -> s_waitcnt vmcnt(0) -> workgroup barrier -> plain loads.
-// (cdna_hip_programming.md Guideline 16, form R1.)  While it waits, a workgroup has
+//   consumer: one lane polls done[b + 1] >= R (relaxed, agent scope, s_sleep) -> workgroup
+//             barrier -> the tile's rows are gathered with sc1 loads (they bypass this CU's L1,
+//             which is all an acquire fence in front of plain loads would have done).
+// (cdna_hip_programming.md Guideline 16, form R1 with sc1 loads in place of the acquire; round 1
+// had the fence -- buffer_inv sc1 + s_waitcnt vmcnt(0), ~1.5 us per hop.)  A tile that is ONE item
+// row does not use the flags at all: it travels through its mailbox (below).  While it waits, a workgroup has
 // already staged the next cell's schedule and gathered its own P rows.  All NP
 // workgroups must be co-resident (the host sizes NP from the occupancy query); every
 // spin is bounded and raises *abort_word instead of hanging.
@@ -654,11 +686,27 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
             const unsigned g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // before arriving
             my_gen = (g0 + 1u) & 0xFFFFu;  // the same in every workgroup of this launch
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // my flags are zero before my arrival counts
+            // Arrival counter: low 31 bits count arrivals, bit 31 says "a waiter has given up".  Giving up and
+            // releasing are decided on this ONE word, so they cannot both happen: a waiter that times out sets the bit
+            // and leaves; the last arriver finds it set and refuses to release (it raises the abort code instead).
+            // (Round 2 had the waiter set the abort word and leave without looking back: the last workgroup could
+            // arrive in that window, release the others and let them train with one workgroup missing.)
+            constexpr unsigned kGaveUp = 0x80000000u;
             const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == (unsigned)NP - 1u) {
-                __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_store(gen, g0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((old & ~kGaveUp) == (unsigned)NP - 1u) {
+                // the last one in: NP -> 0 releases, and only if nobody has set the bit -- one compare-and-swap, so a
+                // waiter's give-up (NP -> NP | bit) and the release exclude each other whichever comes first
+                unsigned expected = (unsigned)NP;
+                if ((old & kGaveUp) == 0u &&
+                    __hip_atomic_compare_exchange_strong(arrive, &expected, 0u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __hip_atomic_store(gen, g0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    expected = 0u;
+                    __hip_atomic_compare_exchange_strong((gu32*)abort_word, &expected, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+                    bad = 2u;  // somebody left: nobody trains (the host zeroes the counter when it handles the abort)
+                }
             } else {
                 unsigned spins = 0;
                 while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) {
@@ -666,6 +714,15 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
                     if ((++spins & 63u) == 0u) {
                         bad = __hip_atomic_load((gu32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (bad == 0u && spins > (1u << 19)) {
+                            // give up -- unless the barrier completed meanwhile: the release zeroes the counter, so a
+                            // release that has happened shows as a count of 0 here; then take the bit back and wait
+                            // for the generation (which the last arriver advances next)
+                            const unsigned was = __hip_atomic_fetch_or(arrive, kGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((was & ~kGaveUp) == 0u) {
+                                __hip_atomic_fetch_and(arrive, ~kGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) __builtin_amdgcn_s_sleep(1);
+                                break;
+                            }
                             unsigned expected = 0u;  // only the first one to give up sets the code
                             __hip_atomic_compare_exchange_strong((gu32*)abort_word, &expected, 2u, __ATOMIC_RELAXED,
                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -815,12 +872,7 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
                         }
                     }
                 }
-#ifdef MFSGD_ACQUIRE_HANDOFF
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-                asm volatile("" ::: "memory");  // the tile's rows are loaded sc1 below: no acquire (it cost ~1.5 us per round)
-#endif
+                asm volatile("" ::: "memory");  // the tile's rows are loaded sc1 below: no acquire fence
             }
         }
         mark(1);  // waiting for the tile (wave 0)
@@ -832,11 +884,7 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         }
         (void)0;
         const bool from_mbox = lone && R > 0;  // the row is in LDS already
-#ifdef MFSGD_ACQUIRE_HANDOFF
-        if (work && !from_mbox) cx.gather(P, Q, cx.nu, cx.nrows);  // the tile's q rows
-#else
         if (work && !from_mbox) cx.template gather<true>(P, Q, cx.nu, cx.nrows);  // the tile's q rows, sc1: stored by another CU
-#endif
         if (work) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows (and the prefetched schedule) have landed
             wg_barrier();

@@ -41,6 +41,13 @@ constexpr int mfsgd_pad_run(int lanes) {
     return 2;
 #endif
 }
+constexpr int mfsgd_pad_gen(int lanes) {
+#ifdef MFSGD_PAD_GEN
+    return MFSGD_PAD_GEN;
+#else
+    return 0;
+#endif
+}
 constexpr int mfsgd_pad_chain(int lanes) {
 #ifdef MFSGD_PAD_CHAIN
     return MFSGD_PAD_CHAIN;
@@ -181,6 +188,102 @@ constexpr int mfsgd_pad_helper(int lanes) {
       "v140", "v141", "v142", "v143"
 
 
+
+// ---- hand-scheduled GENERAL step loop (gfx950) [r3] -------------------------------------------
+// `n` general steps of one wave (kernels.hip Cell::apply, `step`): every lane group applies one rating per step --
+// both rows come from LDS, both go back -- and consecutive steps are independent except where the packer flagged a
+// q row as forwarded (bit 31 of the next entry's slots word: the same item in the same lane slot; its new row is taken
+// from registers, the LDS copy read ahead of the write being stale).  The compiler's schedule of the C++ step waits
+// twice per step for LDS reads it issued a few instructions earlier (~335 cycles per step of G ratings, measured
+// in situ); here the rows of step t + 1 and the entry words of step t + 2 are fetched under the arithmetic of step
+// t with counted waits, as in the run loop above: 24 VALU + 6 LDS instructions per step.
+//   entry (16 bytes per slot and step): {slots = p address | q address << 16 | forward flag << 31 (16-byte units),
+//   rating, lr * rating, decay}; the decay factor of a general step is the uniform c (operand c2 = {c, c}).
+// Register map (two sets, A = even steps, B = odd steps):
+//   v138 entry pointer, v139 row base + this lane's 16-byte offset; v114 / v115 slots word whose rows are fetched
+//   during an odd / even step; v116 / v117 lr*r of the even / odd step; v112, v148 / v113, v149 p and q address of
+//   set A / B; v[104:107], v[100:103] / v[108:111], v[140:143] p and q row of set A / B; v[144:147] the q row read
+//   ahead (selected against the forwarded q'); v[120:121] chunk products, v132 dot, v[122:125] c*q, v[126:129] c*p,
+//   v130 s, v[134:137] p'; q' is computed straight into the OTHER set's q registers.
+// LDS operations of one step, in issue order: read p(t+1), read q(t+1), read slots(t+2), read lr*r(t+1), write p'(t),
+// write q'(t).  LDS operations of a wave complete in order, so "all but the last four" has q(t+1) in registers (the
+// select behind the writes) and "all but the last two" at the top of the next step has the two entry words.
+// Hazards, as the packer guarantees (schedule.cpp, "Eligibility"): a p row never appears in two consecutive steps
+// of a wave; a q row only in the same lane slot, flagged.  Arithmetic: instruction for instruction DESIGN.md section 3.
+#define MFSGD_GEN_HALF(P0, P1, P2, P3, Q0, Q1, Q2, Q3, PADDR, QADDR, NP0, NP3, NQ0, NQ1, NQ2, NQ3, NPADDR, NQADDR, SLOT_NEXT, \
+                       SLOT_NEXT2, OFF_SLOT2, LRR, LRR_NEXT, OFF_LRR1, EXTRA, SFMA)                                              \
+        "s_waitcnt lgkmcnt(2)\n\t" \
+        "v_pk_mul_f32 v[120:121], v[" P0 ":" P1 "], v[" Q0 ":" Q1 "]\n\t" \
+        "v_pk_fma_f32 v[120:121], v[" P2 ":" P3 "], v[" Q2 ":" Q3 "], v[120:121]\n\t" \
+        "v_add_f32 v132, v120, v121\n\t" \
+        "v_mad_u32_u16 v" NPADDR ", v" SLOT_NEXT ", 16, v139\n\t" \
+        "v_bfe_u32 v133, v" SLOT_NEXT ", 16, 15\n\t" \
+        "v_add_f32_dpp v132, v132, v132 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "ds_read_b128 v[" NP0 ":" NP3 "], v" NPADDR "\n\t" \
+        "v_lshl_add_u32 v" NQADDR ", v133, 4, v139\n\t" \
+        "v_add_f32_dpp v132, v132, v132 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "ds_read_b128 v[144:147], v" NQADDR "\n\t" \
+        "v_pk_mul_f32 v[122:123], v[" Q0 ":" Q1 "], %[c2]\n\t" \
+        "v_add_f32_dpp v132, v132, v132 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_pk_mul_f32 v[124:125], v[" Q2 ":" Q3 "], %[c2]\n\t" \
+        "v_pk_mul_f32 v[126:127], v[" P0 ":" P1 "], %[c2]\n\t" \
+        "v_add_f32_dpp v132, v132, v132 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_pk_mul_f32 v[128:129], v[" P2 ":" P3 "], %[c2]\n\t" \
+        "ds_read_b32 v" SLOT_NEXT2 ", v138 offset:" OFF_SLOT2 "\n\t" \
+        "ds_read_b32 v" LRR_NEXT ", v138 offset:" OFF_LRR1 "\n\t" \
+        EXTRA \
+        SFMA(LRR) \
+        "v_pk_fma_f32 v[" NQ0 ":" NQ1 "], v[130:131], v[" P0 ":" P1 "], v[122:123] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 v[" NQ2 ":" NQ3 "], v[130:131], v[" P2 ":" P3 "], v[124:125] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 v[134:135], v[130:131], v[" Q0 ":" Q1 "], v[126:127] op_sel_hi:[0,1,1]\n\t" \
+        "v_pk_fma_f32 v[136:137], v[130:131], v[" Q2 ":" Q3 "], v[128:129] op_sel_hi:[0,1,1]\n\t" \
+        "s_sub_u32 %[n], %[n], 1\n\t" \
+        "v_cmp_gt_i32 vcc, 0, v" SLOT_NEXT "\n\t" \
+        "ds_write_b128 v" PADDR ", v[134:137]\n\t" \
+        "ds_write_b128 v" QADDR ", v[" NQ0 ":" NQ3 "]\n\t" \
+        "s_cmp_eq_u32 %[n], 0\n\t" \
+        "s_waitcnt lgkmcnt(4)\n\t" \
+        "v_cndmask_b32 v" NQ0 ", v144, v" NQ0 ", vcc\n\t" \
+        "v_cndmask_b32 v" NQ1 ", v145, v" NQ1 ", vcc\n\t" \
+        "v_cndmask_b32 v" NQ2 ", v146, v" NQ2 ", vcc\n\t" \
+        "v_cndmask_b32 v" NQ3 ", v147, v" NQ3 ", vcc\n\t"
+
+// `ea`: LDS byte address of this lane group's entry of general step 0 (entry stride EST), n >= 1 steps.
+#define MFSGD_GEN_LOOP_ASM_TEXT(EXTRA, SFMA) \
+        "v_mov_b32 v138, %[ea]\n\t" \
+        "v_mov_b32 v131, %[lr]\n\t" \
+        "v_mov_b32 v139, %[rb]\n\t" \
+        "ds_read_b32 v114, v138\n\t" \
+        "ds_read_b32 v116, v138 offset:8\n\t" \
+        "ds_read_b32 v115, v138 offset:%c[e1]\n\t" \
+        "s_waitcnt lgkmcnt(2)\n\t" \
+        "v_mad_u32_u16 v112, v114, 16, v139\n\t" \
+        "v_bfe_u32 v133, v114, 16, 15\n\t" \
+        "v_lshl_add_u32 v148, v133, 4, v139\n\t" \
+        "ds_read_b128 v[104:107], v112\n\t" \
+        "ds_read_b128 v[100:103], v148\n\t" \
+        "ds_write_b32 v138, v114\n\t" \
+        "ds_write_b32 v138, v114\n\t" \
+        MFSGD_LOOP_ALIGN \
+        "1:\n\t" \
+        MFSGD_GEN_HALF("104", "105", "106", "107", "100", "101", "102", "103", "112", "148", "108", "111", "140", "141", "142", "143", \
+                       "113", "149", "115", "114", "%c[e2]", "116", "117", "%c[e1p8]", EXTRA, SFMA) \
+        "s_cbranch_scc1 2f\n\t" \
+        MFSGD_GEN_HALF("108", "109", "110", "111", "140", "141", "142", "143", "113", "149", "104", "107", "100", "101", "102", "103", \
+                       "112", "148", "114", "115", "%c[e3]", "117", "116", "%c[e2p8]", EXTRA, SFMA) \
+        "v_add_u32 v138, %c[e2], v138\n\t" \
+        "s_cbranch_scc0 1b\n\t" \
+        "2:\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t"
+
+#define MFSGD_GEN_LOOP_ASM_OPERANDS                                                                                    \
+    : [n] "+s"(n)                                                                                                      \
+    : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [c2] "s"(c2), [e1] "n"(EST), [e2] "n"(2 * EST), [e3] "n"(3 * EST), \
+      [e1p8] "n"(EST + 8), [e2p8] "n"(2 * EST + 8), [pad] "n"(PADV)                                                    \
+    : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
+      "v112", "v113", "v114", "v115", "v116", "v117", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127",  \
+      "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141",  \
+      "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149"
 
 // ---- chain wave -------------------------------------------------------------------------------
 // v138 entry pointer (-> entry t at the top of half A), v139 row base + this lane's 16-byte offset;

@@ -1378,27 +1378,31 @@ void dsgd_plan_users(const int64_t* degu, int32_t U, int32_t G, int32_t* user_be
     user_begin[G] = U;
 }
 
-// Items -> G partitions, balanced by rating count AND chain-aware.
+// Items -> G partitions, balanced by rating count; optionally chain-aware (chain_crit > 0).
 //
-// A DSGD sub-epoch cannot end before the heaviest item of its partition has seen all of the rank's ratings of it,
-// one dependent update after the other; a rank's epoch is therefore at least the SUM over the partitions of their
-// heaviest items' chains.  Plain LPT deals the G heaviest items out one per partition -- the worst case for that
-// sum (measured, round 2: 87 K dependent steps per rank at N = 8 on the bench workload against 67.9 K on one
-// device).  Items of ONE partition, on the other hand, advance concurrently (each in its own tile of the
-// partition's block schedule), so heavy items cost nothing extra when they share a partition.  Hence:
-//   1. items in descending order of rating count; an item is CHAIN-CRITICAL when its chain on one rank
-//      (count / world dependent steps of ~(170 + 2L) cycles) is a sizeable fraction (`crit`, default 0.3) of what
-//      the rank's sub-epoch takes when it is bound by work (the scheduler's own model: c_r cycles per rating per
-//      workgroup, c_0 cycles per round, at the block count that minimises their sum);
-//   2. while chain-critical items remain, the next partition is filled SEQUENTIALLY from the sorted list up to an
-//      equal share of what is left (so the critical items sit in as few partitions as the balance allows, heaviest
-//      together), and closed;
-//   3. the rest is dealt over the remaining partitions longest-processing-time-first, as before;
-//   4. items nobody rated go to the partitions with the fewest rows.
-// Balance: every partition is within one item's count of an equal share of what was left when it was opened.
+// What bounds a DSGD epoch.  A sub-epoch of a rank cannot end before the heaviest item of its partition has seen all
+// of the rank's ratings of it, one dependent update after the other.  Two sums follow from that:
+//   (a) a rank computes for at least the SUM over the partitions of their heaviest items' chains;
+//   (b) a Q block is trained by one rank after the other, so block p needs world x t_p per epoch however the ranks
+//       overlap: the RING's epoch is at least world x the SLOWEST partition.
+// Plain LPT (chain_crit = 0, the default) deals the G heaviest items out one per partition: every partition carries a
+// chain of about the same length, the partitions take the same time, and (b) -- the binding one on a real ring --
+// is as small as the heaviest item allows (its own chain, which no partitioning shortens).  It is the worst case for
+// (a).  The chain-aware mode minimises (a): items in descending order of rating count; an item is CHAIN-CRITICAL
+// when its chain on one rank (count / world steps of ~(170 + 2L) cycles) reaches `chain_crit` of what the rank's
+// sub-epoch takes when it is bound by work (the scheduler's own model); while critical items remain the next partition
+// is filled SEQUENTIALLY from the sorted list up to an equal share of what is left and closed; the rest is dealt
+// LPT over the remaining partitions.  Measured (round 3, one rank of the N = 8 bench job, tools/part_profile.py,
+// chain_crit = 0.3): (a) 116 K -> 33 K steps and the rank's own compute 9.17 -> 8.30 ms per epoch, but the heavy
+// partition takes 1.31 ms against 0.98 ms for the others and 1.14 ms for every LPT partition, so (b) goes from
+// 8 x 1.14 = 9.2 ms to 8 x 1.31 = 10.5 ms: worse on the ring.  Hence off by default; kept for hosts that run the
+// partitions of ONE device back to back (virtual devices, out-of-core Q), where (a) is what counts.
+// Items nobody rated go to the partitions with the fewest rows.  Balance: every partition is within one item's count
+// of an equal share of what was left when it was opened.
 // info (nullable, 4 values): {sum over partitions of their heaviest item's count, chain-critical items,
 // partitions filled sequentially, the criticality threshold (global count)}.
-void dsgd_plan_items(const int64_t* degi, int32_t I, int32_t G, int32_t world, int32_t k, int32_t* item_part, int64_t* info) {
+void dsgd_plan_items(const int64_t* degi, int32_t I, int32_t G, int32_t world, int32_t k, double chain_crit, int32_t* item_part,
+                     int64_t* info) {
     if (world < 1) world = 1;
     std::vector<int32_t> idx;
     idx.reserve((size_t)I);
@@ -1411,7 +1415,7 @@ void dsgd_plan_items(const int64_t* degi, int32_t I, int32_t G, int32_t world, i
     std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return degi[a] > degi[b]; });
     // 1. the threshold
     const Geometry geo = geometry_for_k(k > 0 ? k : 64);
-    double crit = 0.3;
+    double crit = chain_crit;
     if (const char* e = std::getenv("MFSGD_PLAN_CRIT")) crit = std::atof(e);  // A/B measurements; <= 0: plain LPT
     int64_t thr = INT64_MAX;
     if (crit > 0 && G > 1 && total > 0) {
@@ -1484,7 +1488,7 @@ void dsgd_plan_items(const int64_t* degi, int32_t I, int32_t G, int32_t world, i
 void dsgd_plan(const int64_t* degu, const int64_t* degi, int32_t U, int32_t I, int32_t G, int32_t* user_begin,
                int32_t* item_part) {
     dsgd_plan_users(degu, U, G, user_begin);
-    dsgd_plan_items(degi, I, G, G, 64, item_part, nullptr);
+    dsgd_plan_items(degi, I, G, G, 64, 0.0, item_part, nullptr);
 }
 
 }  // namespace mfsgd

@@ -183,10 +183,11 @@ int build_schedule_auto(SchedParams prm, const int32_t* u, const int32_t* i, con
 void dsgd_plan(const int64_t* degu, const int64_t* degi, int32_t U, int32_t I, int32_t G, int32_t* user_begin,
                int32_t* item_part);
 // The two halves (schedule.cpp): users over `G` ranks; items over `G` partitions of a job of `world` ranks at rank
-// k -- balanced by rating count and chain-aware (the chain-critical items packed into as few partitions as the
-// balance allows).  info (nullable): {sum of the partitions' heaviest items, critical items, partitions filled
+// k -- balanced by rating count (LPT) and, for chain_crit > 0, chain-aware (the chain-critical items packed into as
+// few partitions as the balance allows; schedule.cpp says when that pays and when it does not).  info (nullable): {sum of the partitions' heaviest items, critical items, partitions filled
 // sequentially, threshold}.
 void dsgd_plan_users(const int64_t* degu, int32_t U, int32_t G, int32_t* user_begin);
-void dsgd_plan_items(const int64_t* degi, int32_t I, int32_t G, int32_t world, int32_t k, int32_t* item_part, int64_t* info);
+void dsgd_plan_items(const int64_t* degi, int32_t I, int32_t G, int32_t world, int32_t k, double chain_crit, int32_t* item_part,
+                     int64_t* info);
 
 }  // namespace mfsgd

@@ -114,11 +114,74 @@ def make_ratings(U, I, nnz, k, dist="uniform", seed=0, k_true=16, noise=0.1, **k
     return u, i, r
 
 
-def workload(name, scale=1.0, seed_offset=0, item_mult=1):
+def make_ratings_device(U, I, nnz, k, dist="zm", seed=0, k_true=16, noise=0.1, s_user=1.0, s_item=1.0, q_user=0.0,
+                        q_item=0.0, device="cuda", user_range=None, log=None):
+    """The `zm` generator of make_ratings on the GPU (torch ops: plumbing for device memory, not the product):
+    the same construction -- Zipf-Mandelbrot draws by inverse CDF, pairs de-duplicated, popularity rank -> random
+    id, rank-k_true ground truth plus noise -- with torch's generator instead of numpy's, so the SAME distribution
+    but a DIFFERENT sample than the host generator (the workload dict says which one made it).  It exists for the
+    sizes the host generator needs half an hour for (BASELINE configs[4]: 1 B ratings): seconds here.
+    user_range = (lo, hi), or a function (deg_user, deg_item) -> (lo, hi) called with the GLOBAL rating counts per
+    row (numpy int64): keep only the ratings of users lo <= u < hi -- a DSGD rank's shard of the global set (every
+    rank generates the same global set from the same seed on its own GPU, derives the same plan from the same
+    degrees and keeps its range; nothing is exchanged and the global set never exists on a host).
+    Returns host numpy arrays (u, i, r): the C-ABI takes host pointers."""
+    import torch
+
+    if dist != "zm":
+        raise ValueError("the device generator implements the zm distribution only")
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed) * 7919 + 13)
+    cu = torch.cumsum(torch.from_numpy(zm_weights(U, s_user, q_user)).to(dev), 0)
+    ci = torch.cumsum(torch.from_numpy(zm_weights(I, s_item, q_item)).to(dev), 0)
+
+    def draw(cdf, m):
+        x = torch.searchsorted(cdf, torch.rand(m, generator=g, device=dev, dtype=torch.float64), right=True)
+        return x.clamp_(max=cdf.numel() - 1)
+
+    key = torch.empty(0, dtype=torch.int64, device=dev)
+    chunk = 250_000_000  # candidates per pass: bounds the sort's temporaries (~3 x 8 bytes each)
+    while key.numel() < nnz:
+        m = min(chunk, int((nnz - key.numel()) * 1.25) + 1024)
+        cand = draw(cu, m) * I + draw(ci, m)
+        key = torch.unique(torch.cat([key, cand]))
+        del cand
+        if log:
+            log(f"  device generator: {key.numel()} distinct pairs of {nnz}")
+    key = key[torch.randperm(key.numel(), generator=g, device=dev)[:nnz]]  # a random subset, in random order
+    pu = torch.randperm(U, generator=g, device=dev)  # popularity rank -> random id
+    pi = torch.randperm(I, generator=g, device=dev)
+    u = pu[key // I]
+    i = pi[key % I]
+    del key, pu, pi, cu, ci
+    if user_range is not None:
+        if callable(user_range):
+            user_range = user_range(torch.bincount(u, minlength=U).cpu().numpy(), torch.bincount(i, minlength=I).cpu().numpy())
+        keep = (u >= user_range[0]) & (u < user_range[1])
+        u, i = u[keep], i[keep]
+        del keep
+    scale = math.sqrt(12.0 / k_true)
+    Pt = torch.rand((U, k_true), generator=g, device=dev, dtype=torch.float32) * scale
+    Qt = torch.rand((I, k_true), generator=g, device=dev, dtype=torch.float32) * scale
+    n = u.numel()
+    r = torch.empty(n, dtype=torch.float32, device=dev)
+    step = 50_000_000
+    for a in range(0, n, step):
+        b = min(a + step, n)
+        r[a:b] = (Pt[u[a:b]] * Qt[i[a:b]]).sum(1) + torch.randn(b - a, generator=g, device=dev) * noise
+    out = (u.to(torch.int32).cpu().numpy(), i.to(torch.int32).cpu().numpy(), r.cpu().numpy())
+    del u, i, r, Pt, Qt
+    torch.cuda.empty_cache()
+    return out
+
+
+def workload(name, scale=1.0, seed_offset=0, item_mult=1, generator="host", user_range=None, log=None):
     """Ratings of a named workload; scale < 1 shrinks U, I and nnz together
     (for parity tests at sizes the oracle finishes in seconds); seed_offset
     gives each DSGD rank its own users and ratings; item_mult widens the item
-    catalogue (weak scaling over N GPUs: N times the items, same ratings per rank)."""
+    catalogue (weak scaling over N GPUs: N times the items, same ratings per rank).
+    generator = "device": make_ratings_device (zm workloads; another sample of the same distribution)."""
     w = dict(WORKLOADS[name])
     w["seed"] = w["seed"] + seed_offset
     if item_mult != 1:
@@ -139,5 +202,13 @@ def workload(name, scale=1.0, seed_offset=0, item_mult=1):
                     w[q] = w[q] * scale
     k = w["k"]
     args = {x: w[x] for x in w if x not in ("k",)}
-    u, i, r = make_ratings(k=k, **args)
-    return dict(U=w["U"], I=w["I"], nnz=w["nnz"], k=k, u=u, i=i, r=r, name=name, dist=w["dist"])
+    if generator == "device":
+        u, i, r = make_ratings_device(k=k, user_range=user_range, log=log, **args)
+    else:
+        u, i, r = make_ratings(k=k, **args)
+        if user_range is not None:
+            if callable(user_range):
+                user_range = user_range(np.bincount(u, minlength=w["U"]).astype(np.int64), np.bincount(i, minlength=w["I"]).astype(np.int64))
+            keep = (u >= user_range[0]) & (u < user_range[1])
+            u, i, r = u[keep], i[keep], r[keep]
+    return dict(U=w["U"], I=w["I"], nnz=int(u.size), k=k, u=u, i=i, r=r, name=name, dist=w["dist"], generator=generator)

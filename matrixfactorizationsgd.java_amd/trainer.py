@@ -48,16 +48,17 @@ def dsgd_plan(deg_user, deg_item, n_parts):
     return ub, ip
 
 
-def dsgd_plan_ex(deg_user, deg_item, world, parts_per_rank=1, k=64):
-    """mfsgd_dsgd_plan_ex: (user_begin[world + 1], item_part[n_items] over world * parts_per_rank partitions, info) --
-    chain-aware; info = dict(sum_max_chain, critical_items, sequential_parts, threshold)."""
+def dsgd_plan_ex(deg_user, deg_item, world, parts_per_rank=1, k=64, chain_crit=0.0):
+    """mfsgd_dsgd_plan_ex: (user_begin[world + 1], item_part[n_items] over world * parts_per_rank partitions, info);
+    chain_crit = 0: plain LPT (what a ring wants), > 0: chain-aware packing (include/mfsgd.h);
+    info = dict(sum_max_chain, critical_items, sequential_parts, threshold)."""
     du = np.ascontiguousarray(deg_user, np.int64)
     di = np.ascontiguousarray(deg_item, np.int64)
     ub = np.empty(int(world) + 1, np.int32)
     ip = np.empty(di.size, np.int32)
     info = np.zeros(4, np.int64)
     rc = _lib.load_library().mfsgd_dsgd_plan_ex(_p(du, C.c_int64), _p(di, C.c_int64), du.size, di.size, int(world),
-                                                int(parts_per_rank), int(k), _p(ub, C.c_int32), _p(ip, C.c_int32),
+                                                int(parts_per_rank), int(k), float(chain_crit), _p(ub, C.c_int32), _p(ip, C.c_int32),
                                                 _p(info, C.c_int64))
     if rc != 0:
         raise MfsgdError(rc, "mfsgd_dsgd_plan_ex: bad argument")

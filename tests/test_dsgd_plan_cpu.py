@@ -28,34 +28,38 @@ def test_plan_is_a_balanced_partition(mf, G):
     # a range boundary can be off by at most one user's ratings; LPT by at most one item's
     assert shard.max() - shard.min() <= 2 * du.max()
     assert part.max() - part.min() <= di.max()
-    # (rows are NOT balanced any more: a partition of heavy items has few of them -- test_plan_is_chain_aware)
+    rows = np.bincount(ip, minlength=G)
+    assert rows.max() - rows.min() <= max(2, I // (4 * G))
     ub2, ip2 = mf.dsgd_plan(du, di, G)  # deterministic
     np.testing.assert_array_equal(ub, ub2)
     np.testing.assert_array_equal(ip, ip2)
 
 
-def test_plan_is_chain_aware(mf, monkeypatch):
-    """A rank's epoch is at least the sum over the partitions of their heaviest items' chains.  Plain LPT deals the G
-    heaviest items out one per partition (the worst case for that sum); the chain-aware plan packs the chain-critical
-    items together: the sum drops, the rating-count balance stays within one item, the heavy partitions are the first
-    ones and are filled in descending order, and mfsgd_dsgd_plan is mfsgd_dsgd_plan_ex(world = n_parts, 1, k = 64)."""
+def test_plan_chain_aware_mode(mf):
+    """mfsgd_dsgd_plan_ex's chain-aware mode (chain_crit > 0): plain LPT (chain_crit = 0, = mfsgd_dsgd_plan) deals the G
+    heaviest items out one per partition -- equal partition times, what a ring wants, but the worst case for the SUM
+    over the partitions of their heaviest items' chains; the chain-aware mode packs the chain-critical items together:
+    the sum drops, the rating-count balance stays within one item, the heavy partitions are the first ones and are
+    filled in descending order."""
     U, I, G = 50000, 9000, 8
     rng = np.random.default_rng(5)
     di = (2.0e6 / (np.arange(I) + 20.0)).astype(np.int64) + 1  # Zipf-Mandelbrot head: ~100 K, 95 K, 91 K, ...
     di = di[rng.permutation(I)]
     di[rng.choice(I, 50, replace=False)] = 0  # a few items nobody rated
     du = np.full(U, di.sum() // U, np.int64)
-    ub, ip, info = mf.dsgd_plan_ex(du, di, G, 1, 64)
-    ub1, ip1 = mf.dsgd_plan(du, di, G)
-    np.testing.assert_array_equal(ip, ip1)
-    np.testing.assert_array_equal(ub, ub1)
+    ub, ip, info = mf.dsgd_plan_ex(du, di, G, 1, 64, chain_crit=0.3)
     load = np.bincount(ip, weights=di, minlength=G)
     assert load.max() - load.min() <= di.max()
     heaviest = np.array([di[ip == p].max() for p in range(G)])
     assert info["sum_max_chain"] == heaviest.sum() and info["critical_items"] > G and 1 <= info["sequential_parts"] < G
-    monkeypatch.setenv("MFSGD_PLAN_CRIT", "0")  # plain LPT
-    _, ip_lpt, info_lpt = mf.dsgd_plan_ex(du, di, G, 1, 64)
+    ub_lpt, ip_lpt, info_lpt = mf.dsgd_plan_ex(du, di, G, 1, 64)  # plain LPT
+    ub1, ip1 = mf.dsgd_plan(du, di, G)
+    np.testing.assert_array_equal(ip_lpt, ip1)
+    np.testing.assert_array_equal(ub_lpt, ub1)
+    np.testing.assert_array_equal(ub_lpt, ub)
     assert info_lpt["critical_items"] == 0 and info_lpt["sequential_parts"] == 0
+    rows_lpt = np.bincount(ip_lpt, minlength=G)
+    assert rows_lpt.max() - rows_lpt.min() <= max(2, I // (4 * G))  # LPT + unrated items dealt out: even row counts
     load_lpt = np.bincount(ip_lpt, weights=di, minlength=G)
     assert load_lpt.max() - load_lpt.min() <= di.max()
     assert info["sum_max_chain"] < 0.5 * info_lpt["sum_max_chain"], (info, info_lpt)
@@ -64,8 +68,7 @@ def test_plan_is_chain_aware(mf, monkeypatch):
         assert di[(ip == p) & (di > 0)].min() >= di[ip == p + 1].max()  # (unrated items are dealt out by row count)
     assert (ip[di >= info["threshold"]] < info["sequential_parts"]).all()
     # two partitions per rank: the same items, cut into twice as many partitions
-    monkeypatch.delenv("MFSGD_PLAN_CRIT")
-    ub2, ip2, info2 = mf.dsgd_plan_ex(du, di, G, 2, 64)
+    ub2, ip2, info2 = mf.dsgd_plan_ex(du, di, G, 2, 64, chain_crit=0.3)
     assert ub2.size == G + 1 and ip2.max() == 2 * G - 1
     load2 = np.bincount(ip2, weights=di, minlength=2 * G)
     assert load2.max() - load2.min() <= di.max()

@@ -1029,7 +1029,7 @@ def test_compiled_cpp_host_example(mf, oracle):
     assert os.path.exists(exe), "build it with __graft_entry__.build()"
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert p.returncode == 0, p.stdout
-    got = [float(x) for x in re.findall(r"epoch \d+ rmse ([0-9.]+)", p.stdout)]
+    got = [float(x) for x in re.findall(r"^epoch \d+ rmse ([0-9.]+)", p.stdout, re.M)]
     pred = float(re.search(r"predict\(3,4\) = ([-0-9.]+)", p.stdout).group(1))
     U, I, k = 100, 80, 8
     u = np.repeat(np.arange(U), I).astype(np.int32)
