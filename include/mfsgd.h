@@ -194,8 +194,8 @@ int mfsgd_get_order(const mfsgd_handle* h, int32_t part, int64_t* order, int64_t
  * subs: n_subs x 2 words {off | solo steps << 16, general steps | run steps << 16};
  * entries: n_entries x 4 words {p addr | q addr << 16 | flag << 31 (16-byte units), rating bits,
  * bits of lr*rating, bits of the slot's decay factor}.  A sub-cell's solo run follows its run steps
- * and two idle steps (padded to whole steps): header {0, slots_0, 0, 0}, then per step {bits of lr*rating, slots of the
- * NEXT step, 0xFFFFFFFF (mailbox), rating bits}, then a terminator; the slots behind the last step
+ * and two idle steps (padded to whole steps): header {slots_0, 0, 0, 0}, then per step {slots of the NEXT step,
+ * 0xFFFFFFFF (mailbox), bits of lr*rating, rating bits}, then a terminator; the slots behind the last step
  * address an all-zero row.                                                                      */
 int mfsgd_debug_schedule_sizes(const mfsgd_handle* h, int32_t part, int64_t* n_cells, int64_t* n_rows,
                                int64_t* n_subs, int64_t* n_entries);

@@ -484,9 +484,9 @@ struct Cell {
                 if constexpr (TRAIN) lds_st(lr_, rqa, rq);
             }
             if (TRAIN && nsolo > 0) {
-                // Solo run: header record, then one 16-byte record per step {lr*r, next slots, mailbox, r}.
+                // Solo run: header record, then one 16-byte record per step {next slots, mailbox, lr*r, r}.
                 const uint4* hdr = lent + (size_t)((offs & 0xFFFF) + n + nr + kSoloPad) * G;
-                const unsigned s0 = hdr->y;
+                const unsigned s0 = hdr->x;
                 const unsigned rqa = (__builtin_amdgcn_ubfe(s0, 16, 15) << 4) + lo;
                 if constexpr (TRAIN && NH > 0 && L >= 16) {
                     // chain wave: dot -> s -> q' only; its helper (a copy wave) stores the p rows and q
@@ -503,11 +503,11 @@ struct Cell {
                         const uint4 e = hdr[1 + t];
                         const float4 p = lds_ld(lr_, pa);
                         const float dot = group_allreduce<L>(chunk_dot(p, q));
-                        const float sc = __builtin_fmaf(-lr, dot, __builtin_bit_cast(float, e.x));
+                        const float sc = __builtin_fmaf(-lr, dot, __builtin_bit_cast(float, e.z));
                         const float4 p2 = axpy_row(sc, q, c, p);
                         q = axpy_row(sc, p, c, q);
                         lds_st(lr_, pa, p2);
-                        pa = ((e.y & 0xFFFFu) << 4) + lo;
+                        pa = ((e.x & 0xFFFFu) << 4) + lo;
                     }
                     lds_st(lr_, rqa, q);
                 }
@@ -537,12 +537,12 @@ struct Cell {
                 if (nsolo == 0) continue;
                 const int nall = __builtin_amdgcn_readfirstlane((int)sd.y);
                 const uint4* hdr = lent + (size_t)((offs & 0xFFFF) + (nall & 0xFFFF) + (int)((unsigned)nall >> 16) + kSoloPad) * G;
-                const float4 q = lds_ld(lr_, (__builtin_amdgcn_ubfe(hdr->y, 16, 15) << 4) + lo);
+                const float4 q = lds_ld(lr_, (__builtin_amdgcn_ubfe(hdr->x, 16, 15) << 4) + lo);
                 for (int t0 = wave_all * G; t0 < nsolo; t0 += NWV * G) {
                     const int t = t0 + g;
                     const bool live = t < nsolo;
                     const uint4 e = hdr[1 + (live ? t : nsolo)];  // past the end: the terminator (r = 0)
-                    const unsigned sl = hdr[live ? t : nsolo].y;    // ... whose predecessor addresses the zero row
+                    const unsigned sl = hdr[live ? t : nsolo].x;    // ... whose predecessor addresses the zero row
                     const float4 p = lds_ld(lr_, ((sl & 0xFFFFu) << 4) + lo);
                     const float err = __builtin_bit_cast(float, e.w) - group_allreduce<L>(chunk_dot(p, q));
                     acc += (double)err * (double)err;

@@ -556,16 +556,17 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
                         unsigned wd[4];
                         const int tt = x2 - 1;  // step of this record (-1: header)
                         auto slots_of = [&](int s2) { return s2 < nsolo ? enc_slots(rat_p[list[s2]], q, false, L) : zero_slots; };
+                        // record = {slots of the NEXT step, mailbox, lr * r, r} (schedule.cpp pack_solo)
                         if (x2 == 0) {
-                            wd[0] = 0u; wd[1] = slots_of(0); wd[2] = 0u; wd[3] = 0u;
+                            wd[0] = slots_of(0); wd[1] = 0u; wd[2] = 0u; wd[3] = 0u;
                         } else if (tt < nsolo) {
                             const float rr = rat_r[list[tt]];
-                            wd[0] = __builtin_bit_cast(unsigned, lr * rr);
-                            wd[1] = slots_of(tt + 1);
-                            wd[2] = 0xFFFFFFFFu;
+                            wd[0] = slots_of(tt + 1);
+                            wd[1] = 0xFFFFFFFFu;
+                            wd[2] = __builtin_bit_cast(unsigned, lr * rr);
                             wd[3] = __builtin_bit_cast(unsigned, rr);
                         } else {
-                            wd[0] = 0u; wd[1] = zero_slots; wd[2] = 0xFFFFFFFFu; wd[3] = 0u;
+                            wd[0] = zero_slots; wd[1] = 0xFFFFFFFFu; wd[2] = 0u; wd[3] = 0u;
                         }
                         Entry e;
                         __builtin_memcpy(&e, wd, 16);

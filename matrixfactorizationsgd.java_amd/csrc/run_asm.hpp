@@ -7,8 +7,8 @@
 //
 // A solo run of n steps is a compact stream of 16-byte entries in the LDS schedule image:
 //     [header][entry 0] ... [entry n-1][terminator]
-//     entry t   = { lr * r_t,  slots_{t+1},  mailbox_t,  r_t }
-//     header    = { 0,         slots_0,      0,          0   }
+//     entry t   = { slots_{t+1},  mailbox_t,  lr * r_t,  r_t }      ([r3] order: {slots, mailbox} is an aligned 8-byte
+//     header    = { slots_0,      0,          0,         0   }       unit, see the helper wave below)
 //     slots_t   = p-row LDS address | q-row LDS address << 16 (16-byte units); slots_n (in entry
 //                 n-1 and in the terminator) addresses an all-zero row
 //     mailbox_t = 0xFFFFFFFF in the schedule; the chain wave overwrites it with the bits of s_t,
@@ -59,7 +59,7 @@ constexpr int mfsgd_pad_helper(int lanes) {
 #ifdef MFSGD_PAD_HELPER
     return MFSGD_PAD_HELPER;
 #else
-    return lanes == 32 ? 0 : 4;
+    return lanes == 16 ? 6 : 2;  // [r3] the loop that takes the steps in pairs (tools/ubench3, profiles/r03_ubench3.log)
 #endif
 }
 #define MFSGD_LOOP_ALIGN ".p2align 6\n\t.rept %c[pad]\n\ts_nop 0\n\t.endr\n\t"
@@ -301,7 +301,7 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "ds_read_b128 v[" N0 ":" N3 "], v113\n\t" \
         "v_pk_mul_f32 v[124:125], v[102:103], %[c2]\n\t" \
         "v_add_f32_dpp v132, v132, v132 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "ds_read_b64 v[" NEXTE "], v138 offset:" OFF_NEXT "\n\t" \
+        "ds_read2_b32 v[" NEXTE "], v138 " OFF_NEXT "\n\t" \
         "s_nop 0\n\t" \
         "v_add_f32_dpp v132, v132, v132 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
         "s_sub_u32 %[n], %[n], 1\n\t" \
@@ -317,8 +317,8 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "v_mov_b32 v138, %[ea]\n\t" \
         "v_mov_b32 v131, %[lr]\n\t" \
         "v_mov_b32 v139, %[rb]\n\t" \
-        "ds_read_b32 v133, v138 offset:4\n\t" \
-        "ds_read_b64 v[116:117], v138 offset:16\n\t" \
+        "ds_read_b32 v133, v138\n\t" \
+        "ds_read2_b32 v[116:117], v138 offset0:6 offset1:4\n\t" \
         "v_mov_b32 v100, %[q0]\n\t" \
         "v_mov_b32 v101, %[q1]\n\t" \
         "v_mov_b32 v102, %[q2]\n\t" \
@@ -326,20 +326,20 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "s_waitcnt lgkmcnt(1)\n\t" \
         "v_mad_u32_u16 v113, v133, 16, v139\n\t" \
         "ds_read_b128 v[104:107], v113\n\t" \
-        "ds_write_b32 v138, v133 offset:4\n\t" \
+        "ds_write_b32 v138, v133\n\t" \
         "s_nop 1\n\t" \
         "v_add_u32 v138, 16, v138\n\t" \
         MFSGD_LOOP_ALIGN \
         "1:\n\t" \
-        MFSGD_SOLO_CHAIN_HALF("104", "105", "106", "107", "108", "109", "110", "111", "116", "117", "118:119", "16", "1", "130", "131", EXTRA, SFMA) \
+        MFSGD_SOLO_CHAIN_HALF("104", "105", "106", "107", "108", "109", "110", "111", "116", "117", "118:119", "offset0:6 offset1:4", "1", "130", "131", EXTRA, SFMA) \
         "s_cbranch_scc1 2f\n\t" \
-        MFSGD_SOLO_CHAIN_HALF("108", "109", "110", "111", "104", "105", "106", "107", "118", "119", "116:117", "32", "0", "128", "129", EXTRA, SFMA) \
-        "ds_write2_b32 v138, v130, v128 offset0:2 offset1:6\n\t" \
+        MFSGD_SOLO_CHAIN_HALF("108", "109", "110", "111", "104", "105", "106", "107", "118", "119", "116:117", "offset0:10 offset1:8", "0", "128", "129", EXTRA, SFMA) \
+        "ds_write2_b32 v138, v130, v128 offset0:1 offset1:5\n\t" \
         "v_add_u32 v138, 32, v138\n\t" \
         "s_cbranch_scc0 1b\n\t" \
         "s_branch 3f\n\t" \
         "2:\n\t" \
-        "ds_write_b32 v138, v130 offset:8\n\t" \
+        "ds_write_b32 v138, v130 offset:4\n\t" \
         "3:\n\t" \
         "s_waitcnt lgkmcnt(0)\n\t" \
         "v_mov_b32 %[q0], v100\n\t" \
@@ -355,16 +355,26 @@ constexpr int mfsgd_pad_helper(int lanes) {
       "v131", "v132", "v133", "v138", "v139"
 
 // ---- helper wave ------------------------------------------------------------------------------
-// v138 entry pointer (-> entry t at the top of half A), v139 row base + lane offset; v[100:103] q_t;
-// v[104:107] / v[108:111] p row of the even / odd step; v[116:117] / v[118:119] {mailbox_t = s_t,
-// slots_{t+1}} of the even / odd step; v112 / v113 p address of the even / odd step; v140 q address;
-// v[122:125] c*q, v[126:129] c*p, v[134:137] p'.  %[spins]: polls left before giving up (the chain
-// wave always arrives; the bound only keeps a broken schedule from hanging the GPU) -- on return
-// %[spins] == 0 means it gave up and nothing further was written.
-#ifndef MFSGD_HV
-#define MFSGD_HV 2
-#endif
-// fast path falls through; the re-poll loop of half TAG sits out of line (MFSGD_SOLO_HELPER_SLOW)
+// [r3] The helper takes the steps in PAIRS, as the chain wave posts them: ONE ds_read2_b64 fetches {slots_{t+1}, s_t}
+// and {slots_{t+2}, s_{t+1}} -- bytes 4..11 of two consecutive entries; the address is 4 modulo 8, which the LDS of
+// gfx9 takes in the unaligned mode the driver runs it in -- one poll test per pair (both mailboxes: v_max_u32 is all
+// ones iff either is), and the loop counter per pair.  Round 2's loop read {s, slots} per step with a ds_read2_b32 and
+// tested per step: 130 cycles per step at 16 lanes per rating against the chain wave's 120, so the pair ran at the
+// helper's pace.  A last odd step (posted alone by the chain wave) is a tail of its own.
+// v138 -> entry t + 4 at the top of a pair; v139 row base + lane offset; v[100:103] q_t; v[104:107] / v[108:111] p row
+// of the pair's first / second step, v112 / v113 their addresses; v[116:119] <-> v[150:153] the pair's words
+// {slots_{t+1}, s_t, slots_{t+2}, s_{t+1}} (s is the HIGH half of an aligned register pair: op_sel:[1,0,0]); v140 q
+// address; v[122:125] c*q, v[126:129] c*p, v[134:137] p'.  %[spins]: polls left before giving up (the chain wave
+// always arrives; the bound only keeps a broken schedule from hanging the GPU) -- on return %[spins] == 0 means it
+// gave up and nothing further was written.
+// LDS operations of a pair, in issue order: read p_{t+1}, read the next pair's words, write p'_t, read p_{t+2}, write
+// p'_{t+1}: "all but the last one" at the top of the next pair has its words and its first p row.
+// NOTHING of the rows is read before s_0 has been posted: the chain wave runs the general and run steps of its sub-cell
+// before the solo run, and they may update the p rows the run is about to use (the helper starts with the sub-round).
+// Once s_0 is there they are final -- only the helper writes them.  (A first version of this loop fetched p_0 in its
+// prologue, in front of the poll: bit-exact in tools/ubench3 -- which has no general steps -- and wrong in the product
+// whenever a user of step 0 also had a general step in the sub-cell.  tools/ubench3 now dirties p_0 first.)
+#ifdef MFSGD_HELPER_PER_STEP  // round 2's per-step helper on the new record layout (A/B, bisecting)
 #define MFSGD_SOLO_HELPER_HALF(TAG, P0, P1, P2, P3, N0, N3, MBOX, MSLOT, MPAIR, NEXTM, PADDR, NADDR, OFF0, OFF1) \
         "s_waitcnt lgkmcnt(1)\n\t" \
         "v_cmp_eq_u32 vcc, -1, v" MBOX "\n\t" \
@@ -400,8 +410,8 @@ constexpr int mfsgd_pad_helper(int lanes) {
 #define MFSGD_SOLO_HELPER_ASM_TEXT \
         "v_mov_b32 v138, %[ea]\n\t" \
         "v_mov_b32 v139, %[rb]\n\t" \
-        "ds_read_b32 v133, v138 offset:4\n\t" \
-        "ds_read2_b32 v[116:117], v138 offset0:6 offset1:5\n\t" \
+        "ds_read_b32 v133, v138\n\t" \
+        "ds_read2_b32 v[116:117], v138 offset0:5 offset1:4\n\t" \
         "s_waitcnt lgkmcnt(1)\n\t" \
         "v_mad_u32_u16 v112, v133, 16, v139\n\t" \
         "v_bfe_u32 v140, v133, 16, 15\n\t" \
@@ -411,7 +421,7 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "s_cbranch_vccz 4f\n\t" \
         "3:\n\t" \
         "s_sleep 1\n\t" \
-        "ds_read_b32 v116, v138 offset:24\n\t" \
+        "ds_read_b32 v116, v138 offset:20\n\t" \
         "s_sub_u32 %[spins], %[spins], 1\n\t" \
         "s_cmp_eq_u32 %[spins], 0\n\t" \
         "s_cbranch_scc1 9f\n\t" \
@@ -421,14 +431,14 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "4:\n\t" \
         "ds_read_b128 v[100:103], v140\n\t" \
         "ds_read_b128 v[104:107], v112\n\t" \
-        "ds_write_b32 v138, v133 offset:4\n\t" \
+        "ds_write_b32 v138, v133\n\t" \
         "s_nop 1\n\t" \
         "v_add_u32 v138, 16, v138\n\t" \
         MFSGD_LOOP_ALIGN \
         "5:\n\t" \
-        MFSGD_SOLO_HELPER_HALF("0", "104", "105", "106", "107", "108", "111", "116", "117", "116:117", "118:119", "112", "113", "offset0:6 offset1:5", "8") \
+        MFSGD_SOLO_HELPER_HALF("0", "104", "105", "106", "107", "108", "111", "116", "117", "116:117", "118:119", "112", "113", "offset0:5 offset1:4", "4") \
         "s_cbranch_scc1 8f\n\t" \
-        MFSGD_SOLO_HELPER_HALF("1", "108", "109", "110", "111", "104", "107", "118", "119", "118:119", "116:117", "113", "112", "offset0:10 offset1:9", "24") \
+        MFSGD_SOLO_HELPER_HALF("1", "108", "109", "110", "111", "104", "107", "118", "119", "118:119", "116:117", "113", "112", "offset0:9 offset1:8", "20") \
         "v_add_u32 v138, 32, v138\n\t" \
         "s_cbranch_scc0 5b\n\t" \
         "8:\n\t" \
@@ -436,14 +446,138 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "s_cbranch_scc1 9f\n\t" \
         "ds_write_b128 v140, v[100:103]\n\t" \
         "s_branch 9f\n\t" \
-        MFSGD_SOLO_HELPER_SLOW("0", "116", "8") \
-        MFSGD_SOLO_HELPER_SLOW("1", "118", "24") \
+        MFSGD_SOLO_HELPER_SLOW("0", "116", "4") \
+        MFSGD_SOLO_HELPER_SLOW("1", "118", "20") \
         "9:\n\t" \
         "s_waitcnt lgkmcnt(0)\n\t"
 
+#else
+#ifndef MFSGD_HV
+#define MFSGD_HV 3
+#endif
+#define MFSGD_SOLO_HELPER_PAIR(TAG, M0, M1, M2, M3, N0, N3) \
+        "s_waitcnt lgkmcnt(1)\n\t" \
+        "v_max_u32 v133, v" M1 ", v" M3 "\n\t" \
+        "v_mad_u32_u16 v113, v" M0 ", 16, v139\n\t" \
+        "v_cmp_eq_u32 vcc, -1, v133\n\t" \
+        "v_pk_mul_f32 v[126:127], v[104:105], %[c2]\n\t" \
+        "s_cbranch_vccnz 7" TAG "f\n\t" \
+        "6" TAG ":\n\t" \
+        "ds_read_b128 v[108:111], v113\n\t" \
+        "v_pk_mul_f32 v[128:129], v[106:107], %[c2]\n\t" \
+        "ds_read2_b64 v[" N0 ":" N3 "], v138 offset0:4 offset1:6\n\t" \
+        "v_pk_mul_f32 v[122:123], v[100:101], %[c2]\n\t" \
+        "v_pk_mul_f32 v[124:125], v[102:103], %[c2]\n\t" \
+        "v_pk_fma_f32 v[134:135], v[" M0 ":" M1 "], v[100:101], v[126:127] op_sel:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[136:137], v[" M0 ":" M1 "], v[102:103], v[128:129] op_sel:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[100:101], v[" M0 ":" M1 "], v[104:105], v[122:123] op_sel:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[102:103], v[" M0 ":" M1 "], v[106:107], v[124:125] op_sel:[1,0,0]\n\t" \
+        "s_sub_u32 %[n], %[n], 2\n\t" \
+        "ds_write_b128 v112, v[134:137]\n\t" \
+        "v_mad_u32_u16 v112, v" M2 ", 16, v139\n\t" \
+        "s_waitcnt lgkmcnt(2)\n\t" \
+        "ds_read_b128 v[104:107], v112\n\t" \
+        "v_pk_mul_f32 v[126:127], v[108:109], %[c2]\n\t" \
+        "v_pk_mul_f32 v[128:129], v[110:111], %[c2]\n\t" \
+        "v_pk_mul_f32 v[122:123], v[100:101], %[c2]\n\t" \
+        "v_pk_mul_f32 v[124:125], v[102:103], %[c2]\n\t" \
+        "v_pk_fma_f32 v[134:135], v[" M2 ":" M3 "], v[100:101], v[126:127] op_sel:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[136:137], v[" M2 ":" M3 "], v[102:103], v[128:129] op_sel:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[100:101], v[" M2 ":" M3 "], v[108:109], v[122:123] op_sel:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[102:103], v[" M2 ":" M3 "], v[110:111], v[124:125] op_sel:[1,0,0]\n\t" \
+        "v_add_u32 v138, 32, v138\n\t" \
+        "s_cmp_lt_u32 %[n], 2\n\t" \
+        "ds_write_b128 v113, v[134:137]\n\t"
+
+// re-poll of a pair whose s has not been posted yet (out of line)
+#define MFSGD_SOLO_HELPER_SLOW(TAG, M0, M1, M3) \
+        "7" TAG ":\n\t" \
+        "s_sleep 1\n\t" \
+        "ds_read2_b64 v[" M0 ":" M3 "], v138 offset1:2\n\t" \
+        "s_sub_u32 %[spins], %[spins], 1\n\t" \
+        "s_cmp_eq_u32 %[spins], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_max_u32 v133, v" M1 ", v" M3 "\n\t" \
+        "v_cmp_eq_u32 vcc, -1, v133\n\t" \
+        "s_cbranch_vccnz 7" TAG "b\n\t" \
+        "s_branch 6" TAG "b\n\t"
+
+// the last step of an odd-length run: its s is posted alone, behind the chain wave's loop
+#define MFSGD_SOLO_HELPER_TAIL(TAG, M0, M1) \
+        "8" TAG ":\n\t" \
+        "s_cmp_eq_u32 %[n], 0\n\t" \
+        "s_cbranch_scc1 40f\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_pk_mul_f32 v[126:127], v[104:105], %[c2]\n\t" \
+        "v_pk_mul_f32 v[128:129], v[106:107], %[c2]\n\t" \
+        "v_pk_mul_f32 v[122:123], v[100:101], %[c2]\n\t" \
+        "v_pk_mul_f32 v[124:125], v[102:103], %[c2]\n\t" \
+        "3" TAG ":\n\t" \
+        "v_cmp_eq_u32 vcc, -1, v" M1 "\n\t" \
+        "s_cbranch_vccz 2" TAG "f\n\t" \
+        "s_sleep 1\n\t" \
+        "ds_read_b32 v" M1 ", v138 offset:4\n\t" \
+        "s_sub_u32 %[spins], %[spins], 1\n\t" \
+        "s_cmp_eq_u32 %[spins], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "s_branch 3" TAG "b\n\t" \
+        "2" TAG ":\n\t" \
+        "v_pk_fma_f32 v[134:135], v[" M0 ":" M1 "], v[100:101], v[126:127] op_sel:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[136:137], v[" M0 ":" M1 "], v[102:103], v[128:129] op_sel:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[100:101], v[" M0 ":" M1 "], v[104:105], v[122:123] op_sel:[1,0,0]\n\t" \
+        "v_pk_fma_f32 v[102:103], v[" M0 ":" M1 "], v[106:107], v[124:125] op_sel:[1,0,0]\n\t" \
+        "s_nop 0\n\t" \
+        "ds_write_b128 v112, v[134:137]\n\t"
+
+#define MFSGD_SOLO_HELPER_ASM_TEXT \
+        "v_mov_b32 v141, %[ea]\n\t" \
+        "v_mov_b32 v139, %[rb]\n\t" \
+        "ds_read_b32 v133, v141\n\t" \
+        "v_add_u32 v138, 16, v141\n\t" \
+        "3:\n\t" \
+        "ds_read2_b64 v[116:119], v138 offset1:2\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_cmp_eq_u32 vcc, -1, v117\n\t" \
+        "s_cbranch_vccz 4f\n\t" \
+        "s_sleep 1\n\t" \
+        "s_sub_u32 %[spins], %[spins], 1\n\t" \
+        "s_cmp_eq_u32 %[spins], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "s_branch 3b\n\t" \
+        "4:\n\t" \
+        "v_mad_u32_u16 v112, v133, 16, v139\n\t" \
+        "v_bfe_u32 v140, v133, 16, 15\n\t" \
+        "v_lshl_add_u32 v140, v140, 4, v139\n\t" \
+        "ds_read_b128 v[100:103], v140\n\t" \
+        "ds_read_b128 v[104:107], v112\n\t" \
+        "ds_write_b32 v141, v133\n\t" \
+        "s_cmp_lt_u32 %[n], 2\n\t" \
+        "s_cbranch_scc1 80f\n\t" \
+        MFSGD_LOOP_ALIGN \
+        "5:\n\t" \
+        MFSGD_SOLO_HELPER_PAIR("0", "116", "117", "118", "119", "150", "153") \
+        "s_cbranch_scc1 81f\n\t" \
+        MFSGD_SOLO_HELPER_PAIR("1", "150", "151", "152", "153", "116", "119") \
+        "s_cbranch_scc0 5b\n\t" \
+        MFSGD_SOLO_HELPER_TAIL("0", "116", "117") \
+        "s_branch 40f\n\t" \
+        MFSGD_SOLO_HELPER_TAIL("1", "150", "151") \
+        "40:\n\t" \
+        "s_cmp_eq_u32 %[fin], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "ds_write_b128 v140, v[100:103]\n\t" \
+        "s_branch 9f\n\t" \
+        MFSGD_SOLO_HELPER_SLOW("0", "116", "117", "119") \
+        MFSGD_SOLO_HELPER_SLOW("1", "150", "151", "153") \
+        "9:\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t"
+
+#endif
 #define MFSGD_SOLO_HELPER_OPERANDS                                                                                     \
     : [n] "+s"(n), [spins] "+s"(spins)                                                                                 \
     : [ea] "v"(ea), [rb] "v"(rowbase), [c2] "s"(c2), [fin] "s"(fin), [pad] "n"(PADV)                                                                 \
     : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110",  \
       "v111", "v112", "v113", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",  \
-      "v129", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140"
+      "v129", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v150", "v151", "v152", "v153"

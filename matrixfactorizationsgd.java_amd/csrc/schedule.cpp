@@ -352,8 +352,10 @@ void pack_run(const Rat* rs, int n, const uint16_t* run_q, int nrun, int G, int 
 
 // A SOLO run: the ratings of ONE item whose users are all distinct, as a compact stream of 16-byte
 // records (kernels.hip, run_asm.hpp): [header][record 0] ... [record n-1][terminator], padded to
-// whole steps.  record t = {lr * r_t, slots_{t+1}, mailbox (0xFFFFFFFF), r_t}; header = {0, slots_0,
+// whole steps.  record t = {slots_{t+1}, mailbox (0xFFFFFFFF), lr * r_t, r_t}; header = {slots_0, 0,
 // 0, 0}; slots = p-row address | q-row address << 16; the address behind the last step is a zero row.
+// ([r3] word order: {slots, mailbox} is an aligned 8-byte unit, so the helper wave fetches the words of TWO
+// steps with one ds_read2_b64 -- run_asm.hpp.)
 // Every step decays with the same factor (no idle slots), so none is stored.
 void pack_solo(const Rat* rs, int n, int G, int Lg, int nrows, const Hyper& hy, std::vector<Entry>& entries,
                std::vector<int64_t>& order, uint32_t& n_units) {
@@ -371,14 +373,14 @@ void pack_solo(const Rat* rs, int n, int G, int Lg, int nrows, const Hyper& hy, 
     const uint32_t q = rs[0].q;
     const uint32_t zero_slots = encode_slots(nrows, (int)q, false, Lg);
     auto slots_of = [&](int t) { return t < n ? encode_slots(rs[t].p, (int)q, false, Lg) : zero_slots; };
-    entries.push_back(words(0u, slots_of(0), 0u, 0u));
+    entries.push_back(words(slots_of(0), 0u, 0u, 0u));
     for (int t = 0; t < n; ++t) {
-        entries.push_back(words(bits(hy.lr * rs[t].r), slots_of(t + 1), 0xFFFFFFFFu, bits(rs[t].r)));
+        entries.push_back(words(slots_of(t + 1), 0xFFFFFFFFu, bits(hy.lr * rs[t].r), bits(rs[t].r)));
         order.push_back(rs[t].idx);
     }
-    entries.push_back(words(0u, zero_slots, 0xFFFFFFFFu, 0u));
+    entries.push_back(words(zero_slots, 0xFFFFFFFFu, 0u, 0u));
     n_units = (uint32_t)((n + 2 + G - 1) / G);
-    for (int x = n + 2; x < (int)n_units * G; ++x) entries.push_back(words(0u, zero_slots, 0xFFFFFFFFu, 0u));
+    for (int x = n + 2; x < (int)n_units * G; ++x) entries.push_back(words(zero_slots, 0xFFFFFFFFu, 0u, 0u));
 }
 
 }  // namespace

@@ -124,16 +124,16 @@ def _replay_chunk(oracle, P, Q, k, lr, lam, sched, cell, W, G, L):
                     if nsolo > 0:
                         first = (ent_off + off + ng + nr + 2) * G  # two idle steps (look-ahead padding) first
                         hdr = entries[first]
-                        pa, qa, _ = _decode(hdr[1], L)
-                        assert qa < nrows and hdr[0] == 0
+                        pa, qa, _ = _decode(hdr[0], L)  # record = {slots of the next step, mailbox, lr * r, r}
+                        assert qa < nrows and hdr[1] == 0
                         q = lds[qa].copy()  # the helper wave reads it once and stores it at the end
                         seen = set()
                         c = np.float32(1.0) - np.float32(lr) * np.float32(lam)
                         for t in range(nsolo):
                             rec = entries[first + 1 + t]
                             r = float(rec[3:4].view(np.float32)[0])
-                            assert rec[0:1].view(np.float32)[0] == np.float32(lr) * np.float32(r)
-                            assert rec[2] == 0xFFFFFFFF, "mailbox must start out empty"
+                            assert rec[2:3].view(np.float32)[0] == np.float32(lr) * np.float32(r)
+                            assert rec[1] == 0xFFFFFFFF, "mailbox must start out empty"
                             assert pa < nu and pa not in seen, "solo run: a user row twice (its helper stores p rows late)"
                             seen.add(pa)
                             for row in (pa, qa):
@@ -141,11 +141,11 @@ def _replay_chunk(oracle, P, Q, k, lr, lam, sched, cell, W, G, L):
                             p2 = lds[pa].copy()
                             oracle.sgd_update(p2, q, r, lr, lam)
                             lds[pa] = p2
-                            pa, qn, _ = _decode(rec[1], L)
+                            pa, qn, _ = _decode(rec[0], L)
                             assert qn == qa
                         assert pa == nrows, "the address behind the last solo step must be the zero row"
                         term = entries[first + 1 + nsolo]
-                        assert _decode(term[1], L)[0] == nrows and term[0] == 0 and term[3] == 0 and term[2] == 0xFFFFFFFF
+                        assert _decode(term[0], L)[0] == nrows and term[2] == 0 and term[3] == 0 and term[1] == 0xFFFFFFFF
                         lds[qa] = q
             assert not lds[nrows:].any(), "an idle slot dirtied the all-zero rows"
             P[ids[:nu]] = lds[:nu]

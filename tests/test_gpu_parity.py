@@ -621,6 +621,22 @@ def test_dsgd8_planned_virtual_devices(mf, oracle, name, scale):
     assert sum(x["nnz"] for row in infos for x in row) == w["nnz"]
 
 
+def test_cfg4_one_eighth_dsgd8_virtual_devices(mf, oracle):
+    """BASELINE configs[4] (power-law popularity, k = 256, DSGD x 8) at ONE EIGHTH of its full size -- what the 8-GPU job
+    gives one GPU: 125 M ratings, 1.25 M x 125 K -- as 8 virtual devices on this GPU: the global set (made on the GPU:
+    synth.make_ratings_device) cut by the product's partitioner, 64 device-built schedules, real kernels, blocks rotated
+    by pointer, one epoch, factors and SSE bit for bit against the sequential DSGD definition (the oracle runs every
+    (device, partition) block multithreaded).  Round 2 ran this builder-side only (tests/gpu_large_extra.py)."""
+    w = mf.synth.workload("cfg4_powerlaw", 0.125, generator="device")
+    assert w["nnz"] == 125_000_000 and w["k"] == 256
+    rm, ub, ip, infos = _virtual_dsgd(mf, oracle, w, 8, 1, mt_threads=16, host_threads=16)
+    du = np.bincount(w["u"], minlength=w["U"])
+    shard = np.array([du[ub[g]:ub[g + 1]].sum() for g in range(8)])
+    assert shard.max() <= 1.01 * shard.mean() + du.max()
+    assert sum(x["nnz"] for row in infos for x in row) == w["nnz"]
+    assert all(x["device_ingest"] == 2 for row in infos for x in row)
+
+
 def test_dsgd_planned_three_devices_chunked(mf, oracle):
     """Odd device count, one block per partition: every partition is chunked (k = 256)."""
     rng = np.random.default_rng(31)
