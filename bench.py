@@ -218,7 +218,9 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
     if args.rehearse_on_one_gpu:
+        # the rehearsal transport is not in the product library: this rank loads libmfsgd_rehearsal.so instead
         os.environ["MFSGD_DSGD_TRANSPORT"] = "shm"  # read by mfsgd_dsgd_unique_id on rank 0
+        os.environ.setdefault("MFSGD_LIBRARY", os.path.join(ROOT, "matrixfactorizationsgd.java_amd", "lib", "libmfsgd_rehearsal.so"))
         args.round_launch = True
 
     rank = int(os.environ.get("RANK", "0"))

@@ -11,6 +11,12 @@ def library_path():
     return os.environ.get("MFSGD_LIBRARY") or os.path.join(_HERE, "lib", "libmfsgd.so")
 
 
+def rehearsal_library_path():
+    """libmfsgd_rehearsal.so: libmfsgd.so plus the DSGD ring's shared-memory rehearsal transport (several ranks on one
+    GPU).  Tests and bench.py --rehearse-on-one-gpu point MFSGD_LIBRARY at it; the product library does not contain it."""
+    return os.path.join(_HERE, "lib", "libmfsgd_rehearsal.so")
+
+
 class Config(C.Structure):
     _fields_ = [
         ("n_users", C.c_int32),

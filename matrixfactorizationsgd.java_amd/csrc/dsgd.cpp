@@ -90,13 +90,17 @@ Rccl& rccl() {
 thread_local std::string g_dsgd_error;
 
 // ---- the rehearsal transport: blocks staged through POSIX shared memory ------------------------------
+// [r3] NOT in the product library: compiled only with -DMFSGD_DSGD_REHEARSAL, i.e. into lib/libmfsgd_rehearsal.so (the
+// Makefile builds it beside libmfsgd.so from the same sources), which the multi-process tests and bench.py
+// --rehearse-on-one-gpu load through MFSGD_LIBRARY.  libmfsgd.so moves blocks with RCCL or not at all.
 // RCCL cannot put two ranks on one GPU, and a host without RCCL has no ring at all.  With
 // MFSGD_DSGD_TRANSPORT=shm mfsgd_dsgd_unique_id() hands out the name of a shared-memory segment instead of
 // an RCCL id, and a ring created from such an id moves its blocks device -> segment -> device with blocking
 // copies and sequence counters.  Same ring, same order of events, no xGMI: it exists so that the multi-rank
 // logic of this file (groups, slots, double buffering, event ordering, the RMSE reduction) runs -- and is
 // tested -- with several REAL processes on one GPU.  Not a performance path.
-constexpr char kShmMagic[8] = {'M', 'F', 'S', 'G', 'D', 'S', 'H', 'M'};
+constexpr char kShmMagic[8] = {'M', 'F', 'S', 'G', 'D', 'S', 'H', 'M'};  // an id that names a segment, not an RCCL id
+#ifdef MFSGD_DSGD_REHEARSAL
 constexpr int kShmMaxWorld = 16, kShmMaxSlots = 64;
 struct ShmHeader {
     std::atomic<uint32_t> ready[kShmMaxWorld];
@@ -129,6 +133,9 @@ bool spin_until(Pred ok, double seconds) {
     }
     return true;
 }
+#else
+struct ShmRing;  // (the product library has no such transport: the pointer below stays null)
+#endif  // MFSGD_DSGD_REHEARSAL
 
 }  // namespace
 
@@ -186,6 +193,7 @@ int dfail(mfsgd_dsgd* d, int code, const std::string& msg) {
 // One ring shift of slot j: the block goes to rank - 1, the next one arrives from rank + 1.
 int shift_slot(mfsgd_dsgd* d, int j, bool after_training) {
     const size_t count = (size_t)d->max_rows * d->kp;
+#ifdef MFSGD_DSGD_REHEARSAL
     if (d->shm) {
         // rehearsal transport: the same shift with blocking copies through shared memory
         ShmRing& r = *d->shm;
@@ -208,6 +216,7 @@ int shift_slot(mfsgd_dsgd* d, int j, bool after_training) {
         DHIP(d, hipEventRecord(d->arrived[(size_t)j], d->wire));
         return MFSGD_OK;
     }
+#endif  // MFSGD_DSGD_REHEARSAL
     Rccl& R = rccl();
     if (after_training) DHIP(d, hipStreamWaitEvent(d->wire, d->trained[(size_t)j], 0));
     DNCCL(d, R.GroupStart());
@@ -288,6 +297,7 @@ int local_sse(mfsgd_dsgd* d, double* out) {
 }
 
 int allreduce2(mfsgd_dsgd* d, double* v, ncclRedOp_t op) {
+#ifdef MFSGD_DSGD_REHEARSAL
     if (d->shm) {
         ShmRing& r = *d->shm;
         ShmHeader* H = r.hdr();
@@ -318,6 +328,7 @@ int allreduce2(mfsgd_dsgd* d, double* v, ncclRedOp_t op) {
         H->ar_done[d->rank].store(q, std::memory_order_release);
         return MFSGD_OK;
     }
+#endif  // MFSGD_DSGD_REHEARSAL
     DHIP(d, hipMemcpyAsync(d->d_red, v, 2 * sizeof(double), hipMemcpyHostToDevice, d->wire));
     DNCCL(d, rccl().AllReduce(d->d_red, d->d_red, 2, ncclDouble, op, d->comm, d->wire));
     DHIP(d, hipMemcpyAsync(v, d->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, d->wire));
@@ -334,6 +345,7 @@ const char* mfsgd_dsgd_last_error(const mfsgd_dsgd* d) { return d ? d->err.c_str
 int mfsgd_dsgd_unique_id(void* id_out) {
     if (!id_out) return dfail(nullptr, MFSGD_ERR_INVALID_ARG, "dsgd_unique_id: null argument");
     static_assert(sizeof(ncclUniqueId) <= MFSGD_DSGD_ID_BYTES, "id buffer");
+#ifdef MFSGD_DSGD_REHEARSAL
     if (const char* tr = std::getenv("MFSGD_DSGD_TRANSPORT"))
         if (std::strcmp(tr, "shm") == 0) {
             // the rehearsal transport: the id is the name of a shared-memory segment
@@ -343,6 +355,11 @@ int mfsgd_dsgd_unique_id(void* id_out) {
             std::snprintf(static_cast<char*>(id_out) + 8, MFSGD_DSGD_ID_BYTES - 8, "/mfsgd_%d_%llx", (int)getpid(), (unsigned long long)now);
             return MFSGD_OK;
         }
+#else
+    if (const char* tr = std::getenv("MFSGD_DSGD_TRANSPORT"))
+        if (std::strcmp(tr, "shm") == 0)
+            return dfail(nullptr, MFSGD_ERR_UNSUPPORTED, "MFSGD_DSGD_TRANSPORT=shm: this library has no rehearsal transport; load lib/libmfsgd_rehearsal.so (MFSGD_LIBRARY)");
+#endif
     Rccl& R = rccl();
     if (!R.lib) return dfail(nullptr, MFSGD_ERR_UNSUPPORTED, "RCCL is not available: " + R.why);
     ncclUniqueId id;
@@ -360,7 +377,13 @@ int mfsgd_dsgd_create(mfsgd_handle* h, int32_t rank, int32_t world, const void* 
     const bool use_shm = std::memcmp(id, kShmMagic, sizeof kShmMagic) == 0;
     Rccl& R = rccl();
     if (!use_shm && !R.lib) return dfail(nullptr, MFSGD_ERR_UNSUPPORTED, "RCCL is not available: " + R.why);
+#ifdef MFSGD_DSGD_REHEARSAL
     if (use_shm && world > kShmMaxWorld) return dfail(nullptr, MFSGD_ERR_UNSUPPORTED, "dsgd (shm transport): at most 16 ranks");
+#else
+    if (use_shm)
+        return dfail(nullptr, MFSGD_ERR_UNSUPPORTED, "dsgd_create: the id names a shared-memory segment, and this library has no rehearsal transport; "
+                                                       "load lib/libmfsgd_rehearsal.so (MFSGD_LIBRARY)");
+#endif
     int32_t n_parts = 0, kp = 0, device = 0, k = 0;
     if (mfsgd_get_parts(h, &n_parts, &kp, &device) != MFSGD_OK || mfsgd_get_dims(h, nullptr, nullptr, &k) != MFSGD_OK)
         return dfail(nullptr, MFSGD_ERR_INVALID_ARG, "dsgd_create: bad handle");
@@ -419,6 +442,7 @@ int mfsgd_dsgd_create(mfsgd_handle* h, int32_t rank, int32_t world, const void* 
         if (hip(hipEventCreateWithFlags(&d->trained[(size_t)j], hipEventDisableTiming), "hipEventCreate") ||
             hip(hipEventCreateWithFlags(&d->arrived[(size_t)j], hipEventDisableTiming), "hipEventCreate"))
             return bail(MFSGD_ERR_HIP);
+#ifdef MFSGD_DSGD_REHEARSAL
     if (use_shm) {
         if (d->m > kShmMaxSlots) {
             d->err = "dsgd_create (shm transport): at most 64 partitions per rank";
@@ -457,6 +481,7 @@ int mfsgd_dsgd_create(mfsgd_handle* h, int32_t rank, int32_t world, const void* 
         *out = d;
         return MFSGD_OK;
     }
+#endif  // MFSGD_DSGD_REHEARSAL
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof uid);
     ncclResult_t r = R.CommInitRank(&d->comm, world, uid, rank);
@@ -475,12 +500,14 @@ void mfsgd_dsgd_destroy(mfsgd_dsgd* d) {
     if (d->compute) (void)hipStreamSynchronize(d->compute);
     if (d->wire) (void)hipStreamSynchronize(d->wire);
     if (d->comm) (void)rccl().CommDestroy(d->comm);
+#ifdef MFSGD_DSGD_REHEARSAL
     if (d->shm) {
         if (d->shm->base) (void)munmap(d->shm->base, d->shm->bytes);
         if (d->shm->fd >= 0) (void)close(d->shm->fd);
         if (d->rank == 0 && !d->shm->name.empty()) (void)shm_unlink(d->shm->name.c_str());
         delete d->shm;
     }
+#endif  // MFSGD_DSGD_REHEARSAL
     for (hipEvent_t e : d->trained)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->arrived)

@@ -5,7 +5,10 @@ the blocks travel through the driver's shared-memory rehearsal transport (RCCL c
 one GPU), everything else -- groups, slots, double buffers, event ordering, the RMSE reduction -- is the
 code the RCCL ring runs.
 
-    python tests/dsgd_native_worker.py RANK WORLD PARTS_PER_RANK ID_HEX OUT_DIR
+    python tests/dsgd_native_worker.py RANK WORLD PARTS_PER_RANK OUT_DIR
+
+The rehearsal transport lives in lib/libmfsgd_rehearsal.so only (MFSGD_LIBRARY points at it, MFSGD_DSGD_TRANSPORT=shm
+selects it); rank 0 makes the ring id and leaves it in OUT_DIR/ring.id for the others.
 """
 import os
 import sys
@@ -23,7 +26,24 @@ from tests.dsgd_common import SEED, native_problem, plan_shards, plan_trainer  #
 
 def main():
     rank, world, m = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-    uid, out_dir = bytes.fromhex(sys.argv[4]), sys.argv[5]
+    out_dir = sys.argv[4]
+    id_path = os.path.join(out_dir, "ring.id")
+    if rank == 0:
+        uid = NativeDSGD.unique_id()
+        assert uid[:8] == b"MFSGDSHM"
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(id_path + ".tmp", id_path)
+    else:
+        import time
+
+        t0 = time.time()
+        while not os.path.exists(id_path):
+            if time.time() - t0 > 300:
+                raise SystemExit("rank 0 never wrote the ring id")
+            time.sleep(0.05)
+        with open(id_path, "rb") as f:
+            uid = f.read()
     U, I, k, u, i, r, epochs = native_problem()
     n_parts = world * m
     ub, ip, sel = plan_shards(mf, U, I, u, i, world)  # users over the ranks ...

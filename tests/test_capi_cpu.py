@@ -197,20 +197,52 @@ def test_dsgd_driver_fails_cleanly_without_a_gpu(mf):
         assert ei.value.code in (-2, -3, -4), ei.value
 
 
-def test_dsgd_rehearsal_id_names_a_shared_memory_segment(mf, monkeypatch):
-    """MFSGD_DSGD_TRANSPORT=shm: the 128-byte id is the magic and a segment name (no RCCL, no GPU needed for
-    the id); creating the ring still needs a device and fails cleanly here, leaving no segment behind."""
+def test_dsgd_rehearsal_transport_is_not_in_the_product_library(mf, monkeypatch, tmp_path):
+    """The ring's shared-memory rehearsal transport (several ranks on one GPU) ships in lib/libmfsgd_rehearsal.so only
+    (round 3: it used to sit in the product library behind the environment variable).  libmfsgd.so: MFSGD_DSGD_TRANSPORT
+    = shm is refused, and the library does not even import shm_open; libmfsgd_rehearsal.so: the 128-byte id is the magic
+    and a segment name (no RCCL, no GPU needed for the id), creating the ring still needs a device and fails cleanly
+    here, leaving no segment behind; it exports every symbol of the header too."""
+    import subprocess
+    import sys
+
+    from mfsgd_amd import _lib
     from mfsgd_amd.dsgd import NativeDSGD
 
     monkeypatch.setenv("MFSGD_DSGD_TRANSPORT", "shm")
-    a, b = NativeDSGD.unique_id(), NativeDSGD.unique_id()
-    assert len(a) == 128 and a[:8] == b"MFSGDSHM" and a != b
-    name = a[8:].split(b"\0")[0].decode()
-    assert name.startswith("/mfsgd_")
-    if have_gpu():
-        return
+    with pytest.raises(mf.MfsgdError) as ei:
+        NativeDSGD.unique_id()  # this process holds the product library
+    assert ei.value.code == -6 and "rehearsal" in str(ei.value)
+    fake = b"MFSGDSHM/mfsgd_nowhere" + b"\0" * 106
     with mf.MatrixFactorizationSGD(10, 9, 8, 0.01, 0.05, 1, n_parts=2) as t:
         t.set_ratings([0, 1, 2], [0, 1, 2], [1.0, 2.0, 3.0])
-        with pytest.raises(mf.MfsgdError):
-            NativeDSGD(t, 0, 1, a)
-    assert not os.path.exists("/dev/shm" + name)
+        with pytest.raises(mf.MfsgdError) as ei:
+            NativeDSGD(t, 0, 1, fake)
+        assert ei.value.code == -6
+    nm = subprocess.run(["nm", "-D", _lib.library_path()], stdout=subprocess.PIPE, text=True).stdout
+    assert "shm_open" not in nm and "mfsgd_dsgd_create" in nm
+    nm_r = subprocess.run(["nm", "-D", _lib.rehearsal_library_path()], stdout=subprocess.PIPE, text=True).stdout
+    assert "shm_open" in nm_r
+    for name in _lib.SIGNATURES:
+        assert f" T {name}" in nm_r, name
+    code = (
+        "import os, sys; sys.path.insert(0, os.getcwd())\n"
+        "import mfsgd_amd as mf\n"
+        "from mfsgd_amd.dsgd import NativeDSGD\n"
+        "a, b = NativeDSGD.unique_id(), NativeDSGD.unique_id()\n"
+        "assert len(a) == 128 and a[:8] == b'MFSGDSHM' and a != b\n"
+        "name = a[8:].split(b'\\0')[0].decode(); assert name.startswith('/mfsgd_')\n"
+        "if sys.argv[1] == 'nogpu':\n"
+        "    with mf.MatrixFactorizationSGD(10, 9, 8, 0.01, 0.05, 1, n_parts=2) as t:\n"
+        "        t.set_ratings([0, 1, 2], [0, 1, 2], [1.0, 2.0, 3.0])\n"
+        "        try:\n"
+        "            NativeDSGD(t, 0, 1, a); raise SystemExit('created a ring without a device')\n"
+        "        except mf.MfsgdError:\n"
+        "            pass\n"
+        "    assert not os.path.exists('/dev/shm' + name)\n"
+        "print('ok')\n")
+    env = dict(os.environ, MFSGD_LIBRARY=_lib.rehearsal_library_path(), MFSGD_DSGD_TRANSPORT="shm")
+    p = subprocess.run([sys.executable, "-c", code, "gpu" if have_gpu() else "nogpu"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stdout
+

@@ -900,15 +900,14 @@ def test_native_dsgd_multi_process_shm(mf, oracle, tmp_path, monkeypatch, world,
     import subprocess
     import sys
 
-    from mfsgd_amd.dsgd import NativeDSGD
+    from mfsgd_amd import _lib
     from tests.conftest import ROOT
     from tests.dsgd_common import LAM as DL, LR as DLR, SEED, native_problem, plan_shards, plan_trainer
 
-    monkeypatch.setenv("MFSGD_DSGD_TRANSPORT", "shm")
-    uid = NativeDSGD.unique_id()
-    assert uid[:8] == b"MFSGDSHM"
+    # the rehearsal transport is in lib/libmfsgd_rehearsal.so only: the ranks load that one (this process keeps the product library)
+    env = dict(os.environ, MFSGD_DSGD_TRANSPORT="shm", MFSGD_LIBRARY=_lib.rehearsal_library_path())
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dsgd_native_worker.py"), str(rk), str(world), str(m),
-                               uid.hex(), str(tmp_path)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                               str(tmp_path)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for rk in range(world)]
     outs = []
     for pr in procs:
