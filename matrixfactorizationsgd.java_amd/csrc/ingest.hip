@@ -35,6 +35,7 @@ struct Ctx {
     SubDesc* d_subs = nullptr;
     PackArgs args{};                 // as launched for COUNT; EMIT reuses it
     int64_t n_cells = 0;
+    int rows_full = 0;               // the row capacity no cell (or part of one) can exceed
 };
 
 #define ING_CHK(call)                      \
@@ -336,13 +337,82 @@ int pack_count_cb(void* vctx, const PackRequest& q, std::vector<PackCellInfo>& i
     ING_CHK(hipMemcpy(subs.data(), c->d_subs, sizeof(SubDesc) * (size_t)(n_cells * WW), hipMemcpyDeviceToHost));
     c->args = a;
     c->n_cells = n_cells;
+    c->rows_full = rows_full;
     return 0;
 fail:
     return rc;
 }
 
+// A list of parts (chunks) as the packing kernel's cells: uploads it and returns the arguments of a launch over it
+// (COUNT outputs allocated); the caller frees what `owned` holds.
+struct PartList {
+    unsigned* d_sorted = nullptr;
+    long long* d_cptr = nullptr;
+    PackCellInfo* d_info = nullptr;
+    SubDesc* d_subs = nullptr;
+    void release() {
+        void* ptrs[] = {d_sorted, d_cptr, d_info, d_subs};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        d_sorted = nullptr;
+        d_cptr = nullptr;
+        d_info = nullptr;
+        d_subs = nullptr;
+    }
+};
+
+bool upload_parts(Ctx* c, int64_t n_parts, const uint32_t* sorted, int64_t n_sorted, const int64_t* cptr, PartList& pl, PackArgs& a) {
+    const int64_t WW = (int64_t)c->args.W * c->args.W;
+    static_assert(sizeof(long long) == sizeof(int64_t), "cptr is uploaded as it is");
+    if (hipMalloc(&pl.d_sorted, 4 * (size_t)std::max<int64_t>(n_sorted, 1)) != hipSuccess ||
+        hipMalloc(&pl.d_cptr, 8 * (size_t)(n_parts * WW + 1)) != hipSuccess ||
+        hipMalloc(&pl.d_info, sizeof(PackCellInfo) * (size_t)n_parts) != hipSuccess ||
+        hipMalloc(&pl.d_subs, sizeof(SubDesc) * (size_t)(n_parts * WW)) != hipSuccess ||
+        hipMemcpy(pl.d_sorted, sorted, 4 * (size_t)n_sorted, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(pl.d_cptr, cptr, 8 * (size_t)(n_parts * WW + 1), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        pl.release();
+        return false;
+    }
+    a = c->args;
+    a.max_rows = c->rows_full;  // a part can hold any number of rows a cell can
+    a.sorted = pl.d_sorted;
+    a.bptr = pl.d_cptr;
+    a.info = pl.d_info;
+    a.subs = pl.d_subs;
+    a.emit = 0;
+    return true;
+}
+
+int pack_count_parts_cb(void* vctx, int64_t n_parts, const uint32_t* sorted, int64_t n_sorted, const int64_t* cptr,
+                        PackCellInfo* info, SubDesc* subs) {
+    Ctx* c = static_cast<Ctx*>(vctx);
+    if (!c->d_info || n_parts < 0) return -1;
+    if (n_parts == 0) return 0;
+    const int64_t WW = (int64_t)c->args.W * c->args.W;
+    PartList pl;
+    PackArgs a{};
+    if (!upload_parts(c, n_parts, sorted, n_sorted, cptr, pl, a)) return -1;
+    int rc = -1;
+    ING_CHK(launch_pack(a, n_parts, (hipStream_t)0));
+    ING_CHK(hipMemcpy(info, pl.d_info, sizeof(PackCellInfo) * (size_t)n_parts, hipMemcpyDeviceToHost));
+    ING_CHK(hipMemcpy(subs, pl.d_subs, sizeof(SubDesc) * (size_t)(n_parts * WW), hipMemcpyDeviceToHost));
+    rc = 0;
+fail:
+    pl.release();
+    return rc;
+}
+
+struct PartsToEmit {
+    int64_t n_parts = 0, n_sorted = 0;
+    const uint32_t* sorted = nullptr;
+    const int64_t* cptr = nullptr;
+    const uint32_t *row_off = nullptr, *ent_off = nullptr;
+    const int64_t* ord_off = nullptr;
+};
+
 int emit_common(Ctx* c, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
-                int64_t n_steps, const MixedPieces* host, DevicePacked* out) {
+                int64_t n_steps, const MixedPieces* host, DevicePacked* out, const PartsToEmit* parts = nullptr) {
     if (!c->d_info || !out) return -1;
     PackArgs a = c->args;
     uint32_t *d_ro = nullptr, *d_eo = nullptr, *d_rows = nullptr;
@@ -373,6 +443,39 @@ int emit_common(Ctx* c, const uint32_t* row_off, const uint32_t* ent_off, const 
     a.entries = d_ent;
     a.order = d_order;
     ING_CHK(launch_pack(a, c->n_cells, (hipStream_t)0));
+    if (parts && parts->n_parts > 0) {
+        // the chunks of the cells that were cut: COUNT over the final list (the EMIT pass reads the sub-cell table the
+        // COUNT pass of the SAME list left on the device), then EMIT at the caller's offsets into the same arrays
+        PartList pl;
+        PackArgs pa{};
+        uint32_t *p_ro = nullptr, *p_eo = nullptr;
+        long long* p_oo = nullptr;
+        const size_t np = (size_t)parts->n_parts;
+        bool ok = upload_parts(c, parts->n_parts, parts->sorted, parts->n_sorted, parts->cptr, pl, pa);
+        ok = ok && launch_pack(pa, parts->n_parts, (hipStream_t)0) == hipSuccess;
+        ok = ok && hipMalloc(&p_ro, 4 * np) == hipSuccess && hipMalloc(&p_eo, 4 * np) == hipSuccess && hipMalloc(&p_oo, 8 * np) == hipSuccess;
+        ok = ok && hipMemcpy(p_ro, parts->row_off, 4 * np, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(p_eo, parts->ent_off, 4 * np, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(p_oo, parts->ord_off, 8 * np, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) {
+            pa.emit = 1;
+            pa.row_off = p_ro;
+            pa.ent_off = p_eo;
+            pa.ord_off = p_oo;
+            pa.rows = d_rows;
+            pa.entries = d_ent;
+            pa.order = d_order;
+            ok = launch_pack(pa, parts->n_parts, (hipStream_t)0) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        }
+        if (p_ro) (void)hipFree(p_ro);
+        if (p_eo) (void)hipFree(p_eo);
+        if (p_oo) (void)hipFree(p_oo);
+        pl.release();
+        if (!ok) {
+            (void)hipGetLastError();
+            goto fail;
+        }
+    }
     if (host) {
         // what the host packed: three staging arrays and their segment lists, then one copy kernel each
         if (!stage(0, host->rows.data(), host->rows.size() * 4) || !stage(1, host->seg_rows.data(), host->seg_rows.size() * sizeof(MixedSegment)) ||
@@ -419,6 +522,20 @@ int pack_emit_mixed_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_
     return emit_common(static_cast<Ctx*>(vctx), row_off, ent_off, ord_off, n_rows, n_steps, &host, out);
 }
 
+int pack_emit_parts_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
+                       int64_t n_steps, int64_t n_parts, const uint32_t* sorted, int64_t n_sorted, const int64_t* cptr,
+                       const uint32_t* p_row_off, const uint32_t* p_ent_off, const int64_t* p_ord_off, DevicePacked* out) {
+    PartsToEmit pe;
+    pe.n_parts = n_parts;
+    pe.n_sorted = n_sorted;
+    pe.sorted = sorted;
+    pe.cptr = cptr;
+    pe.row_off = p_row_off;
+    pe.ent_off = p_ent_off;
+    pe.ord_off = p_ord_off;
+    return emit_common(static_cast<Ctx*>(vctx), row_off, ent_off, ord_off, n_rows, n_steps, nullptr, out, &pe);
+}
+
 int download_cb(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* entries, int64_t n_entries, int64_t* order,
                 int64_t n) {
     if (rows && n_rows > 0 && hipMemcpy(rows, d.rows, 4 * (size_t)n_rows, hipMemcpyDeviceToHost) != hipSuccess) return -1;
@@ -429,7 +546,8 @@ int download_cb(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* en
     return 0;
 }
 
-const DeviceIngestExt kExt = {bucket_dev_cb, fetch_sorted_cb, fetch_sorted32_cb, pack_count_cb, pack_emit_cb, pack_emit_mixed_cb, download_cb};
+const DeviceIngestExt kExt = {bucket_dev_cb, fetch_sorted_cb, fetch_sorted32_cb, pack_count_cb, pack_emit_cb, pack_emit_mixed_cb,
+                              pack_count_parts_cb, pack_emit_parts_cb, download_cb};
 
 }  // namespace
 

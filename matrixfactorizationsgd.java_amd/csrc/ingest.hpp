@@ -82,6 +82,18 @@ struct DeviceIngestExt {
     // EMIT for the cells whose row_off is not 0xFFFFFFFF, then the host-packed pieces scattered to their places
     int (*pack_emit_mixed)(void* ctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
                            int64_t n_steps, const MixedPieces& host, DevicePacked* out) = nullptr;
+    // [r3] Chunks on the device.  A chunk of a cell is a subset of its ratings (those inside a rectangle of user and
+    // item ids, schedule.cpp) packed as a complete little cell; to the packing kernel it IS a cell, given as a list:
+    // `sorted` = rating indices of the parts one after another, each in the cell's bucket order, `cptr` = n_parts * W*W
+    // + 1 sub-cell starts into that list.  COUNT over such a list (any number of times, between pack_count and the
+    // emit): info[n_parts], subs[n_parts * W*W].  Returns 0, or -1 when a HIP call failed.
+    int (*pack_count_parts)(void* ctx, int64_t n_parts, const uint32_t* sorted, int64_t n_sorted, const int64_t* cptr,
+                            PackCellInfo* info, SubDesc* subs) = nullptr;
+    // EMIT for the whole cells whose row_off is not 0xFFFFFFFF AND for a final list of parts (the chunks of the cells
+    // that were cut), each at the offsets the caller gives (p_*: per part), into ONE set of arrays
+    int (*pack_emit_parts)(void* ctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
+                           int64_t n_steps, int64_t n_parts, const uint32_t* sorted, int64_t n_sorted, const int64_t* cptr,
+                           const uint32_t* p_row_off, const uint32_t* p_ent_off, const int64_t* p_ord_off, DevicePacked* out) = nullptr;
     // device -> host copies of what emit() produced (debug / get_order); any pointer may be null
     int (*download)(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* entries, int64_t n_entries, int64_t* order,
                     int64_t n) = nullptr;

@@ -13,6 +13,7 @@
 #include <iterator>
 #include <numeric>
 #include <queue>
+#include <mutex>
 #include <thread>
 
 namespace mfsgd {
@@ -127,6 +128,12 @@ struct CellOut {
     uint32_t n_rows = 0;
     int64_t n_order = 0;
     bool dev = false;  // packed by the device packer: rows / entries / order are not here
+    // [r3] a CHUNK the device packs (a part of a cell that was cut): its ratings as indices into the caller's arrays, in
+    // the cell's bucket order, with the sub-cell of each -- the packing kernel takes the list as a cell of its own
+    bool dev_part = false;
+    std::vector<uint32_t> part_idx;
+    std::vector<uint16_t> part_sb;
+    mutable int64_t desc = -1;  // its chunk descriptor, once placed
 };
 
 struct Scratch {
@@ -856,6 +863,11 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         for (auto& t : th) t.join();
     };
 
+    // [r3] Mixed mode with the chunks packed on the device as well (pack_count_parts / pack_emit_parts): the host only
+    // DECIDES the cuts -- from the cells' ids -- and asks the device for the size of every candidate chunk.
+    // MFSGD_HOST_CHUNKS=1: round 2's mixed mode (the host packs and chunks what the device declines; A/B measurements).
+    const bool dev_chunks = have_info && ext && ext->pack_count_parts && ext->pack_emit_parts && !sorted32.empty() &&
+                            !std::getenv("MFSGD_HOST_CHUNKS");
     // Phase 1: every cell as a single chunk, unless it cannot possibly fit.
     std::vector<CellOut> co((size_t)ncell);
     std::vector<uint8_t> oversize((size_t)ncell, 0);
@@ -875,7 +887,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     const PackCellInfo& ci = info[(size_t)c];
                     const int nrows = (int)(ci.nu + ci.ni);
                     if (ci.status == 0 && addressable(nrows) && rows_bytes_for(geo, nrows) + 2 * min_sched <= avail) {
-                        o.subs.assign(dsubs.begin() + c * WW, dsubs.begin() + (c + 1) * WW);
+                        // (its sub-cell table stays in dsubs: place() takes it from there -- 590 K small vectors less at
+                        // the Netflix shape)
                         o.nu = ci.nu;
                         o.ni = ci.ni;
                         o.n_steps = ci.n_steps;
@@ -886,6 +899,17 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                         o.dev = true;
                         continue;
                     }
+                }
+                if (dev_chunks) {
+                    // [r3] the device packs the chunks too: a cell it declined as ONE chunk (its rows exceed the LDS
+                    // image, or its counters overflowed) is exactly a cell the host packer would call oversize
+                    const PackCellInfo& ci = info[(size_t)c];
+                    o = CellOut{};
+                    o.nu = ci.nu;
+                    o.ni = ci.ni;
+                    o.n_order = bptr[(size_t)((c + 1) * WW)] - bptr[(size_t)(c * WW)];
+                    oversize[(size_t)c] = 1;
+                    continue;
                 }
                 load_cell(c, sel);
                 int nu, ni;
@@ -988,15 +1012,227 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     // Phase 2: cells over the limits are cut in two (by users or by items, whichever there are more
     // of; halves balanced by rating count) until every piece fits.
     std::vector<std::vector<CellOut>> extra((size_t)ncell);
-    {
-        std::vector<int64_t> todo;
-        for (int64_t c = 0; c < ncell; ++c) {
-            const CellOut& o = co[(size_t)c];
-            if (oversize[(size_t)c] ||
-                (o.n_steps != 0 && (sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps) > lim_s ||
-                                    rows_bytes_for(geo, (int)(o.nu + o.ni)) > lim_r)))
-                todo.push_back(c);
+    std::vector<int64_t> todo;
+    for (int64_t c = 0; c < ncell; ++c) {
+        const CellOut& o = co[(size_t)c];
+        if (oversize[(size_t)c] ||
+            (o.n_steps != 0 && (sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps) > lim_s ||
+                                rows_bytes_for(geo, (int)(o.nu + o.ni)) > lim_r)))
+            todo.push_back(c);
+    }
+    if (dev_chunks && !todo.empty()) {
+        // The same cut tree as the host recursion below, grown level by level: a part whose rows fit is a candidate
+        // and the device's COUNT pass says how many steps it packs into; a candidate within the limits is a leaf (a
+        // chunk), everything else is cut at the same pivot the recursion would take.  A leaf's place among its cell's
+        // chunks is its path in the tree (left before right).
+        struct Part {
+            int64_t cell;
+            uint64_t path;  // bit (63 - d) = went right at depth d
+            int depth;
+            std::vector<uint32_t> idx;
+            std::vector<uint16_t> sb;
+            int nu = 0, ni = 0;
+            bool candidate = false;
+            bool by_user = false;   // the cut this part gets if it is not a leaf ...
+            uint32_t pivot = 0;     // ... ids >= pivot go right
+        };
+        struct Leaf {
+            uint64_t path;
+            CellOut o;
+        };
+        std::vector<std::vector<Leaf>> leaves((size_t)todo.size());
+        std::vector<Part> level;
+        level.reserve(todo.size());
+        for (size_t x = 0; x < todo.size(); ++x) {
+            const int64_t c = todo[x];
+            Part p;
+            p.cell = (int64_t)x;
+            p.path = 0;
+            p.depth = 0;
+            const int64_t lo = bptr[(size_t)(c * WW)], hi = bptr[(size_t)((c + 1) * WW)];
+            p.idx.resize((size_t)(hi - lo));
+            p.sb.resize((size_t)(hi - lo));
+            int sbi = 0;
+            for (int64_t y = lo; y < hi; ++y) {
+                while (bptr[(size_t)(c * WW + sbi + 1)] <= y) ++sbi;
+                p.idx[(size_t)(y - lo)] = sorted32[(size_t)y];
+                p.sb[(size_t)(y - lo)] = (uint16_t)sbi;
+            }
+            level.push_back(std::move(p));
         }
+        bool root = true;
+        while (!level.empty() && !failed.load()) {
+            // 1. distinct rows of every part; whole cells (the roots) are known not to fit: they are cut unseen
+            {
+                std::atomic<size_t> nx{0};
+                auto work = [&]() {
+                    std::vector<uint32_t> us, is;
+                    for (;;) {
+                        const size_t x = nx.fetch_add(1);
+                        if (x >= level.size()) break;
+                        Part& p = level[x];
+                        us.resize(p.idx.size());
+                        is.resize(p.idx.size());
+                        for (size_t y = 0; y < p.idx.size(); ++y) {
+                            us[y] = (uint32_t)u[p.idx[y]];
+                            is[y] = (uint32_t)i[p.idx[y]];
+                        }
+                        std::sort(us.begin(), us.end());
+                        std::sort(is.begin(), is.end());
+                        auto distinct = [](const std::vector<uint32_t>& v) {
+                            int n = 0;
+                            for (size_t y = 0; y < v.size(); ++y) n += y == 0 || v[y] != v[y - 1];
+                            return n;
+                        };
+                        p.nu = distinct(us);
+                        p.ni = distinct(is);
+                        const int nrows = p.nu + p.ni;
+                        p.candidate = !root && addressable(nrows) && rows_bytes_for(geo, nrows) <= lim_r;
+                        // the pivot of the cut, should there be one: the first distinct id (position >= 1) at which the
+                        // ratings of the ids before it reach half of the part (the host recursion's rule)
+                        p.by_user = (p.nu >= p.ni && p.nu > 1) || p.ni <= 1;
+                        const std::vector<uint32_t>& v = p.by_user ? us : is;
+                        const int nid = p.by_user ? p.nu : p.ni;
+                        const int64_t half = (int64_t)v.size() / 2;
+                        int seen = 0;  // distinct ids passed
+                        p.pivot = v.empty() ? 0u : v[0];
+                        for (size_t y = 0; y < v.size(); ++y) {
+                            if (y > 0 && v[y] != v[y - 1]) {
+                                // y ratings belong to the `seen + 1` ids before v[y]
+                                ++seen;
+                                p.pivot = v[y];
+                                if ((int64_t)y >= half || seen >= nid - 1) break;
+                            }
+                        }
+                    }
+                };
+                std::vector<std::thread> th;
+                for (int t = 1; t < (int)std::min<size_t>((size_t)nthreads, level.size()); ++t) th.emplace_back(work);
+                work();
+                for (auto& t : th) t.join();
+            }
+            // 2. the candidates' sizes, from the device
+            std::vector<size_t> cand;
+            for (size_t x = 0; x < level.size(); ++x)
+                if (level[x].candidate) cand.push_back(x);
+            std::vector<PackCellInfo> pinfo(cand.size());
+            std::vector<SubDesc> psubs(cand.size() * (size_t)WW);
+            if (!cand.empty()) {
+                std::vector<uint32_t> lst;
+                std::vector<int64_t> cptr(cand.size() * (size_t)WW + 1, 0);
+                for (size_t y = 0; y < cand.size(); ++y) {
+                    const Part& p = level[cand[y]];
+                    size_t at = 0;
+                    for (int sbi = 0; sbi < WW; ++sbi) {
+                        cptr[y * (size_t)WW + (size_t)sbi] = (int64_t)(lst.size() + at);
+                        while (at < p.sb.size() && p.sb[at] == (uint16_t)sbi) ++at;
+                    }
+                    lst.insert(lst.end(), p.idx.begin(), p.idx.end());
+                }
+                cptr[cand.size() * (size_t)WW] = (int64_t)lst.size();
+                if (ext->pack_count_parts(prm.ingest->ctx, (int64_t)cand.size(), lst.data(), (int64_t)lst.size(), cptr.data(),
+                                          pinfo.data(), psubs.data()) != 0) {
+                    err = "build_schedule: the device packer's COUNT pass over the chunks failed";
+                    return -1;
+                }
+            }
+            // 3. leaves and cuts
+            std::vector<Part> next;
+            std::vector<uint8_t> is_leaf(level.size(), 0);
+            for (size_t y = 0; y < cand.size(); ++y) {
+                Part& p = level[cand[y]];
+                const PackCellInfo& ci = pinfo[y];
+                if (ci.status == 0 && sched_bytes_for(geo, W, p.nu + p.ni, (int64_t)ci.n_steps) <= lim_s) {
+                    Leaf lf;
+                    lf.path = p.path;
+                    lf.o.subs.assign(psubs.begin() + (long)(y * (size_t)WW), psubs.begin() + (long)((y + 1) * (size_t)WW));
+                    lf.o.nu = ci.nu;
+                    lf.o.ni = ci.ni;
+                    lf.o.n_steps = ci.n_steps;
+                    lf.o.crit = ci.crit;
+                    lf.o.has_run = ci.has_run != 0;
+                    lf.o.n_rows = ci.nu + ci.ni;
+                    lf.o.n_order = (int64_t)p.idx.size();
+                    lf.o.dev_part = true;
+                    lf.o.part_idx = std::move(p.idx);
+                    lf.o.part_sb = std::move(p.sb);
+                    leaves[(size_t)p.cell].push_back(std::move(lf));
+                    is_leaf[cand[y]] = 1;
+                }
+            }
+            {
+                std::mutex mu;
+                std::atomic<size_t> nx{0};
+                auto work = [&]() {
+                    std::vector<uint32_t> ids;
+                    std::vector<int64_t> cnt;
+                    std::vector<Part> mine;
+                    for (;;) {
+                        const size_t x = nx.fetch_add(1);
+                        if (x >= level.size()) break;
+                        if (is_leaf[x]) continue;
+                        Part& p = level[x];
+                        if (p.idx.size() <= 1) {
+                            if (!failed.exchange(1)) fail_msg = "lds: a single rating does not fit the chunk limits";
+                            break;
+                        }
+                        if (p.depth >= 62) {
+                            if (!failed.exchange(1)) fail_msg = "build_schedule: a cell was cut more than 62 times";
+                            break;
+                        }
+                        Part l, r2;
+                        l.cell = r2.cell = p.cell;
+                        l.depth = r2.depth = p.depth + 1;
+                        l.path = p.path;
+                        r2.path = p.path | (1ull << (63 - p.depth));
+                        if (p.nu <= 1 && p.ni <= 1) {
+                            // the same (user, item) pair many times over: any cut of the sequence will do
+                            const size_t half = p.idx.size() / 2;
+                            l.idx.assign(p.idx.begin(), p.idx.begin() + (long)half);
+                            l.sb.assign(p.sb.begin(), p.sb.begin() + (long)half);
+                            r2.idx.assign(p.idx.begin() + (long)half, p.idx.end());
+                            r2.sb.assign(p.sb.begin() + (long)half, p.sb.end());
+                        } else {
+                            const int32_t* key_of = p.by_user ? u : i;
+                            const uint32_t pivot = p.pivot;
+                            l.idx.reserve(p.idx.size() / 2 + 8);
+                            r2.idx.reserve(p.idx.size() / 2 + 8);
+                            for (size_t y = 0; y < p.idx.size(); ++y) {
+                                Part& dst = (uint32_t)key_of[p.idx[y]] < pivot ? l : r2;
+                                dst.idx.push_back(p.idx[y]);
+                                dst.sb.push_back(p.sb[y]);
+                            }
+                        }
+                        std::vector<uint32_t>().swap(p.idx);
+                        std::vector<uint16_t>().swap(p.sb);
+                        mine.push_back(std::move(l));
+                        mine.push_back(std::move(r2));
+                    }
+                    std::lock_guard<std::mutex> lk(mu);
+                    for (Part& q : mine) next.push_back(std::move(q));
+                };
+                std::vector<std::thread> th;
+                for (int t = 1; t < (int)std::min<size_t>((size_t)nthreads, level.size()); ++t) th.emplace_back(work);
+                work();
+                for (auto& t : th) t.join();
+            }
+            level = std::move(next);
+            root = false;
+        }
+        if (!failed.load()) {
+            for (size_t x = 0; x < todo.size(); ++x) {
+                std::vector<Leaf>& lv = leaves[x];
+                std::sort(lv.begin(), lv.end(), [](const Leaf& a, const Leaf& b) { return a.path < b.path; });
+                if (lv.empty()) {
+                    if (!failed.exchange(1)) fail_msg = "build_schedule: internal error, a cut cell has no chunk";
+                    break;
+                }
+                const int64_t c = todo[x];
+                co[(size_t)c] = std::move(lv[0].o);
+                for (size_t y = 1; y < lv.size(); ++y) extra[(size_t)c].push_back(std::move(lv[y].o));
+            }
+        }
+    } else {
         std::atomic<int64_t> next_todo{0};
         run_parallel([&](Scratch& sc, std::vector<RawRat>& sel) {
             std::vector<CellOut> pieces;
@@ -1101,8 +1337,12 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             cdsc.next = next;
             out.cells[(size_t)d] = cdsc;
             by_desc[(size_t)d] = &o;
-            for (int x = 0; x < WW; ++x)
-                out.subs[(size_t)(d * WW + x)] = o.subs.empty() ? SubDesc{0, 0} : o.subs[(size_t)x];
+            o.desc = d;
+            if (o.dev && o.subs.empty() && d < ncell)
+                std::memcpy(&out.subs[(size_t)(d * WW)], &dsubs[(size_t)(d * WW)], sizeof(SubDesc) * (size_t)WW);
+            else
+                for (int x = 0; x < WW; ++x)
+                    out.subs[(size_t)(d * WW + x)] = o.subs.empty() ? SubDesc{0, 0} : o.subs[(size_t)x];
             tot_rows += (int64_t)o.n_rows;
             tot_steps += o.n_steps;
             if (o.n_steps != 0) {
@@ -1172,20 +1412,44 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         err = "build_schedule: internal error, packed " + std::to_string(pos) + " of " + std::to_string(n);
         return -1;
     }
-    int64_t n_dev_cells = 0;
-    for (int64_t c = 0; c < ncell; ++c) n_dev_cells += co[(size_t)c].dev ? 1 : 0;
-    if (n_dev_cells > 0) {
-        // ---- mixed finish: the device writes its cells at their final places (EMIT pass), what the host
-        // packed (cells that had to be chunked, cells the kernel could not hold) is scattered behind it
+    int64_t n_dev_cells = 0, n_dev_parts = 0;
+    for (int64_t x = 0; x < n_descs; ++x) {
+        n_dev_cells += by_desc[(size_t)x]->dev ? 1 : 0;
+        n_dev_parts += by_desc[(size_t)x]->dev_part ? 1 : 0;
+    }
+    if (n_dev_cells > 0 || n_dev_parts > 0) {
+        // ---- mixed finish: the device writes its cells at their final places (EMIT pass); the chunks of the cells that
+        // were cut are packed there too ([r3], from their rating lists), or -- round 2's form, MFSGD_HOST_CHUNKS -- what
+        // the host packed is scattered behind it
         MixedPieces mp;
         std::vector<uint32_t> row_off((size_t)ncell, 0xFFFFFFFFu), ent_off((size_t)ncell, 0u);
         std::vector<int64_t> ord_off((size_t)ncell, 0);
+        std::vector<uint32_t> p_idx, p_ro, p_eo;
+        std::vector<int64_t> p_cptr, p_oo;
+        std::vector<int64_t> part_of_desc((size_t)n_descs, -1);
+        if (n_dev_parts > 0) {
+            p_ro.reserve((size_t)n_dev_parts);
+            p_eo.reserve((size_t)n_dev_parts);
+            p_cptr.reserve((size_t)(n_dev_parts * WW) + 1);
+        }
         for (int64_t x = 0; x < n_descs; ++x) {
             const CellOut& o = *by_desc[(size_t)x];
             const CellDesc& d = out.cells[(size_t)x];
             if (o.dev) {
                 row_off[(size_t)x] = d.row_off;  // (device cells are first chunks: x < ncell)
                 ent_off[(size_t)x] = d.ent_off;
+                continue;
+            }
+            if (o.dev_part) {
+                part_of_desc[(size_t)x] = (int64_t)p_ro.size();
+                p_ro.push_back(d.row_off);
+                p_eo.push_back(d.ent_off);
+                size_t at = 0;
+                for (int sbi = 0; sbi < WW; ++sbi) {
+                    p_cptr.push_back((int64_t)(p_idx.size() + at));
+                    while (at < o.part_sb.size() && o.part_sb[at] == (uint16_t)sbi) ++at;
+                }
+                p_idx.insert(p_idx.end(), o.part_idx.begin(), o.part_idx.end());
                 continue;
             }
             if (!o.rows.empty()) {
@@ -1197,13 +1461,17 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 mp.entries.insert(mp.entries.end(), o.entries.begin(), o.entries.end());
             }
         }
+        p_cptr.push_back((int64_t)p_idx.size());
+        p_oo.assign(p_ro.size(), 0);
         for (int64_t x = 0; x < ncell; ++x) {
             const int64_t rd = x / B, b = x % B;
             const int64_t c = b * B + (b + rd) % B;
             int64_t at = out.cell_ptr[(size_t)x];
             ord_off[(size_t)c] = at;
             auto piece = [&](const CellOut& o) {
-                if (!o.dev && !o.order.empty()) {
+                if (o.dev_part) {
+                    p_oo[(size_t)part_of_desc[(size_t)o.desc]] = at;
+                } else if (!o.dev && !o.order.empty()) {
                     mp.seg_order.push_back({(uint64_t)at, (uint64_t)mp.order.size(), (uint64_t)o.order.size()});
                     mp.order.insert(mp.order.end(), o.order.begin(), o.order.end());
                 }
@@ -1211,6 +1479,27 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             };
             piece(co[(size_t)c]);
             for (const CellOut& o : extra[(size_t)c]) piece(o);
+        }
+        if (n_dev_parts > 0) {
+            if (!mp.rows.empty() || !mp.entries.empty() || !mp.order.empty()) {
+                err = "build_schedule: internal error, host-packed pieces beside device-packed chunks";
+                return -1;
+            }
+            lap("  mixed: lists of the chunks");
+            if (ext->pack_emit_parts(prm.ingest->ctx, row_off.data(), ent_off.data(), ord_off.data(), tot_rows, tot_steps,
+                                     (int64_t)p_ro.size(), p_idx.data(), (int64_t)p_idx.size(), p_cptr.data(), p_ro.data(), p_eo.data(),
+                                     p_oo.data(), &out.dev.buf) != 0) {
+                err = "build_schedule: the device packer's EMIT pass (cells and chunks) failed";
+                return -1;
+            }
+            lap("  mixed: emit (cells + chunks)");
+            out.device_packed = true;
+            out.dev_ops = ext;
+            out.device_ingest = true;
+            out.n_rows_words = tot_rows + 4;
+            out.n_entry_recs = tot_steps * G;
+            out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+            return 0;
         }
         lap("  mixed: staging of the host-packed pieces");
         if (ext->pack_emit_mixed(prm.ingest->ctx, row_off.data(), ent_off.data(), ord_off.data(), tot_rows, tot_steps, mp,
