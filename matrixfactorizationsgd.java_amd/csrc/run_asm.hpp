@@ -347,78 +347,6 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "v_mov_b32 %[q2], v102\n\t" \
         "v_mov_b32 %[q3], v103\n\t"
 
-// ---- [r3] CONTIGUOUS solo run: the p row of step t sits in row slot (slot of step 0) + t ----------------------------
-// (the packers sort a solo run by row slot; when the run then covers a contiguous range of slots -- a cell that is ONE
-// solo run, which is what an item with a tile of its own gets -- the header's second word says so).  Neither wave needs
-// the slots words then: the p rows are read at a running address with immediate offsets, and the chain wave fetches lr*r
-// of TWO steps with one ds_read2_b32 -- one LDS instruction per pair less on the wave the epoch waits for.
-// Chain wave: v113 = address of p_t at the top of half A; v116 / v118 lr*r of the even / odd step (v119 -> v116 per pair).
-#define MFSGD_SOLO_CHAIN_CONTIG_HALF(P0, P1, P2, P3, N0, N3, ROFF, ELRR, MID, WAIT, S, S1, EXTRA, SFMA) \
-        "s_waitcnt lgkmcnt(" WAIT ")\n\t" \
-        "v_pk_mul_f32 v[120:121], v[" P0 ":" P1 "], v[100:101]\n\t" \
-        "v_pk_fma_f32 v[120:121], v[" P2 ":" P3 "], v[102:103], v[120:121]\n\t" \
-        "v_add_f32 v132, v120, v121\n\t" \
-        "v_pk_mul_f32 v[122:123], v[100:101], %[c2]\n\t" \
-        "v_pk_mul_f32 v[124:125], v[102:103], %[c2]\n\t" \
-        "v_add_f32_dpp v132, v132, v132 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "ds_read_b128 v[" N0 ":" N3 "], v113 offset:" ROFF "\n\t" \
-        MID \
-        "v_add_f32_dpp v132, v132, v132 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "s_sub_u32 %[n], %[n], 1\n\t" \
-        "s_cmp_eq_u32 %[n], 0\n\t" \
-        "v_add_f32_dpp v132, v132, v132 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "s_nop 1\n\t" \
-        "v_add_f32_dpp v132, v132, v132 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        EXTRA \
-        SFMA(S, ELRR) \
-        "v_pk_fma_f32 v[100:101], v[" S ":" S1 "], v[" P0 ":" P1 "], v[122:123] op_sel_hi:[0,1,1]\n\t" \
-        "v_pk_fma_f32 v[102:103], v[" S ":" S1 "], v[" P2 ":" P3 "], v[124:125] op_sel_hi:[0,1,1]\n\t"
-
-#define MFSGD_SOLO_CHAIN_CONTIG_ASM_TEXT(EXTRA, SFMA) \
-        "v_mov_b32 v138, %[ea]\n\t" \
-        "v_mov_b32 v131, %[lr]\n\t" \
-        "v_mov_b32 v139, %[rb]\n\t" \
-        "ds_read_b32 v133, v138\n\t" \
-        "ds_read_b32 v116, v138 offset:24\n\t" \
-        "v_mov_b32 v100, %[q0]\n\t" \
-        "v_mov_b32 v101, %[q1]\n\t" \
-        "v_mov_b32 v102, %[q2]\n\t" \
-        "v_mov_b32 v103, %[q3]\n\t" \
-        "s_waitcnt lgkmcnt(1)\n\t" \
-        "v_mad_u32_u16 v113, v133, 16, v139\n\t" \
-        "ds_read_b128 v[104:107], v113\n\t" \
-        "ds_write_b32 v138, v133\n\t" \
-        "s_nop 1\n\t" \
-        "v_add_u32 v138, 16, v138\n\t" \
-        MFSGD_LOOP_ALIGN \
-        "1:\n\t" \
-        MFSGD_SOLO_CHAIN_CONTIG_HALF("104", "105", "106", "107", "108", "111", "%c[rowb]", "116", \
-                                     "ds_read2_b32 v[118:119], v138 offset0:6 offset1:10\n\t", "1", "130", "131", EXTRA, SFMA) \
-        "s_cbranch_scc1 2f\n\t" \
-        MFSGD_SOLO_CHAIN_CONTIG_HALF("108", "109", "110", "111", "104", "107", "%c[rowb2]", "118", \
-                                     "v_mov_b32 v116, v119\n\t", "0", "128", "129", EXTRA, SFMA) \
-        "ds_write2_b32 v138, v130, v128 offset0:1 offset1:5\n\t" \
-        "v_add_u32 v138, 32, v138\n\t" \
-        "v_add_u32 v113, %c[rowb2], v113\n\t" \
-        "s_cbranch_scc0 1b\n\t" \
-        "s_branch 3f\n\t" \
-        "2:\n\t" \
-        "ds_write_b32 v138, v130 offset:4\n\t" \
-        "3:\n\t" \
-        "s_waitcnt lgkmcnt(0)\n\t" \
-        "v_mov_b32 %[q0], v100\n\t" \
-        "v_mov_b32 %[q1], v101\n\t" \
-        "v_mov_b32 %[q2], v102\n\t" \
-        "v_mov_b32 %[q3], v103\n\t"
-
-#define MFSGD_SOLO_CHAIN_CONTIG_OPERANDS                                                                               \
-    : [n] "+s"(n), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3])                                  \
-    : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [c2] "s"(c2), [pad] "n"(PADV), [rowb] "n"(ROWBYTES),              \
-      [rowb2] "n"(2 * ROWBYTES)                                                                                        \
-    : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
-      "v113", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v128", "v129", "v130",  \
-      "v131", "v132", "v133", "v138", "v139"
-
 #define MFSGD_SOLO_CHAIN_OPERANDS                                                                                      \
     : [n] "+s"(n), [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3])                                  \
     : [ea] "v"(ea), [rb] "v"(rowbase), [lr] "s"(lr), [c2] "s"(c2), [pad] "n"(PADV)                                     \
@@ -561,40 +489,6 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "s_cmp_lt_u32 %[n], 2\n\t" \
         "ds_write_b128 v113, v[134:137]\n\t"
 
-// the same pair for a CONTIGUOUS run: p rows at v112 + {0, rowb, 2 rowb}
-#define MFSGD_SOLO_HELPER_CONTIG_PAIR(TAG, M0, M1, M2, M3, N0, N3) \
-        "s_waitcnt lgkmcnt(1)\n\t" \
-        "v_max_u32 v133, v" M1 ", v" M3 "\n\t" \
-        "v_pk_mul_f32 v[126:127], v[104:105], %[c2]\n\t" \
-        "v_cmp_eq_u32 vcc, -1, v133\n\t" \
-        "v_pk_mul_f32 v[128:129], v[106:107], %[c2]\n\t" \
-        "s_cbranch_vccnz 7" TAG "f\n\t" \
-        "6" TAG ":\n\t" \
-        "ds_read_b128 v[108:111], v112 offset:%c[rowb]\n\t" \
-        "v_pk_mul_f32 v[122:123], v[100:101], %[c2]\n\t" \
-        "ds_read2_b64 v[" N0 ":" N3 "], v138 offset0:4 offset1:6\n\t" \
-        "v_pk_mul_f32 v[124:125], v[102:103], %[c2]\n\t" \
-        "v_pk_fma_f32 v[134:135], v[" M0 ":" M1 "], v[100:101], v[126:127] op_sel:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[136:137], v[" M0 ":" M1 "], v[102:103], v[128:129] op_sel:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[100:101], v[" M0 ":" M1 "], v[104:105], v[122:123] op_sel:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[102:103], v[" M0 ":" M1 "], v[106:107], v[124:125] op_sel:[1,0,0]\n\t" \
-        "s_sub_u32 %[n], %[n], 2\n\t" \
-        "ds_write_b128 v112, v[134:137]\n\t" \
-        "s_waitcnt lgkmcnt(2)\n\t" \
-        "ds_read_b128 v[104:107], v112 offset:%c[rowb2]\n\t" \
-        "v_pk_mul_f32 v[126:127], v[108:109], %[c2]\n\t" \
-        "v_pk_mul_f32 v[128:129], v[110:111], %[c2]\n\t" \
-        "v_pk_mul_f32 v[122:123], v[100:101], %[c2]\n\t" \
-        "v_pk_mul_f32 v[124:125], v[102:103], %[c2]\n\t" \
-        "v_pk_fma_f32 v[134:135], v[" M2 ":" M3 "], v[100:101], v[126:127] op_sel:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[136:137], v[" M2 ":" M3 "], v[102:103], v[128:129] op_sel:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[100:101], v[" M2 ":" M3 "], v[108:109], v[122:123] op_sel:[1,0,0]\n\t" \
-        "v_pk_fma_f32 v[102:103], v[" M2 ":" M3 "], v[110:111], v[124:125] op_sel:[1,0,0]\n\t" \
-        "v_add_u32 v138, 32, v138\n\t" \
-        "ds_write_b128 v112, v[134:137] offset:%c[rowb]\n\t" \
-        "s_cmp_lt_u32 %[n], 2\n\t" \
-        "v_add_u32 v112, %c[rowb2], v112\n\t"
-
 // re-poll of a pair whose s has not been posted yet (out of line)
 #define MFSGD_SOLO_HELPER_SLOW(TAG, M0, M1, M3) \
         "7" TAG ":\n\t" \
@@ -637,7 +531,7 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "s_nop 0\n\t" \
         "ds_write_b128 v112, v[134:137]\n\t"
 
-#define MFSGD_SOLO_HELPER_ASM_TEXT_(PAIR) \
+#define MFSGD_SOLO_HELPER_ASM_TEXT \
         "v_mov_b32 v141, %[ea]\n\t" \
         "v_mov_b32 v139, %[rb]\n\t" \
         "ds_read_b32 v133, v141\n\t" \
@@ -663,9 +557,9 @@ constexpr int mfsgd_pad_helper(int lanes) {
         "s_cbranch_scc1 80f\n\t" \
         MFSGD_LOOP_ALIGN \
         "5:\n\t" \
-        PAIR("0", "116", "117", "118", "119", "150", "153") \
+        MFSGD_SOLO_HELPER_PAIR("0", "116", "117", "118", "119", "150", "153") \
         "s_cbranch_scc1 81f\n\t" \
-        PAIR("1", "150", "151", "152", "153", "116", "119") \
+        MFSGD_SOLO_HELPER_PAIR("1", "150", "151", "152", "153", "116", "119") \
         "s_cbranch_scc0 5b\n\t" \
         MFSGD_SOLO_HELPER_TAIL("0", "116", "117") \
         "s_branch 40f\n\t" \
@@ -679,18 +573,8 @@ constexpr int mfsgd_pad_helper(int lanes) {
         MFSGD_SOLO_HELPER_SLOW("1", "150", "151", "153") \
         "9:\n\t" \
         "s_waitcnt lgkmcnt(0)\n\t"
-#define MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_ASM_TEXT_(MFSGD_SOLO_HELPER_PAIR)
-#define MFSGD_SOLO_HELPER_CONTIG_ASM_TEXT MFSGD_SOLO_HELPER_ASM_TEXT_(MFSGD_SOLO_HELPER_CONTIG_PAIR)
 
 #endif
-#define MFSGD_SOLO_HELPER_CONTIG_OPERANDS                                                                              \
-    : [n] "+s"(n), [spins] "+s"(spins)                                                                                 \
-    : [ea] "v"(ea), [rb] "v"(rowbase), [c2] "s"(c2), [fin] "s"(fin), [pad] "n"(PADV), [rowb] "n"(ROWBYTES),            \
-      [rowb2] "n"(2 * ROWBYTES)                                                                                        \
-    : "memory", "scc", "vcc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110",  \
-      "v111", "v112", "v113", "v116", "v117", "v118", "v119", "v122", "v123", "v124", "v125", "v126", "v127", "v128",  \
-      "v129", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v150", "v151", "v152", "v153"
-
 #define MFSGD_SOLO_HELPER_OPERANDS                                                                                     \
     : [n] "+s"(n), [spins] "+s"(spins)                                                                                 \
     : [ea] "v"(ea), [rb] "v"(rowbase), [c2] "s"(c2), [fin] "s"(fin), [pad] "n"(PADV)                                                                 \

@@ -43,21 +43,8 @@
 #ifndef EXTRA_SOLO
 #define EXTRA_SOLO EXTRA
 #endif
-// -DCONTIG: the loops of a CONTIGUOUS solo run (p row of step t in row slot t), run_asm.hpp
-#ifdef CONTIG
-#define UB_CHAIN_TEXT MFSGD_SOLO_CHAIN_CONTIG_ASM_TEXT
-#define UB_CHAIN_OPS MFSGD_SOLO_CHAIN_CONTIG_OPERANDS
-#define UB_HELPER_TEXT MFSGD_SOLO_HELPER_CONTIG_ASM_TEXT
-#define UB_HELPER_OPS MFSGD_SOLO_HELPER_CONTIG_OPERANDS
-#else
-#define UB_CHAIN_TEXT MFSGD_SOLO_CHAIN_ASM_TEXT
-#define UB_CHAIN_OPS MFSGD_SOLO_CHAIN_OPERANDS
-#define UB_HELPER_TEXT MFSGD_SOLO_HELPER_ASM_TEXT
-#define UB_HELPER_OPS MFSGD_SOLO_HELPER_OPERANDS
-#endif
 
 constexpr int ROWB = 16 * LG;
-[[maybe_unused]] constexpr int ROWBYTES = ROWB;
 constexpr int NSTEP = (LG == 64 ? 120 : LG == 32 ? 200 : 300), NROWS = NSTEP + 2;  // p rows 0..NSTEP-1, q row NSTEP, zero row NSTEP+1
 constexpr int ENT_OFF = NROWS * ROWB;          // entries behind the rows
 constexpr int GS = 64 / LG;                    // slots per step of the (old) run loop
@@ -99,12 +86,12 @@ __global__ void __launch_bounds__(192) k(const float* rows_in, const uint32_t* e
         const int m = (n_steps / 2) & ~1;
         const unsigned ea0 = ea;
         n = m;
-        asm volatile(UB_CHAIN_TEXT(EXTRA_SOLO, SFMA2) UB_CHAIN_OPS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA_SOLO, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
         *(f4*)(smem + NSTEP * ROWB + (lane % LG) * 16) = q;
         {
             const unsigned ea = ea0 + m * 16;
             n = n_steps - m;
-            asm volatile(UB_CHAIN_TEXT(EXTRA_SOLO, SFMA2) UB_CHAIN_OPS);
+            asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA_SOLO, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
         }
     } else if (wave == 0 && mode != 2) {
         typedef float f4 __attribute__((ext_vector_type(4)));
@@ -121,12 +108,12 @@ __global__ void __launch_bounds__(192) k(const float* rows_in, const uint32_t* e
         }
         f4 q = *(const f4*)(smem + NSTEP * ROWB + (lane % LG) * 16);
         constexpr int PADV = mfsgd_pad_chain(LG);
-        asm volatile(UB_CHAIN_TEXT(EXTRA_SOLO, SFMA2) UB_CHAIN_OPS);
+        asm volatile(MFSGD_SOLO_CHAIN_ASM_TEXT(EXTRA_SOLO, SFMA2) MFSGD_SOLO_CHAIN_OPERANDS);
     } else if (wave == 1 && (mode == 0 || mode == 2 || mode == 5)) {
         int spins = 1 << 20, fin = 1;
         asm volatile("" : "+s"(fin));
         constexpr int PADV = mfsgd_pad_helper(LG);
-        asm volatile(UB_HELPER_TEXT UB_HELPER_OPS);
+        asm volatile(MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_OPERANDS);
         if (spins == 0 && lane == 0) cyc[2] = 1;
     } else if ((wave == 1 || wave == 2) && mode == 4) {
         // the two helpers of a cut run: wave 1 follows [0, m) and leaves q alone, wave 2 follows [m, n)
@@ -139,7 +126,7 @@ __global__ void __launch_bounds__(192) k(const float* rows_in, const uint32_t* e
             const unsigned ea = wave == 1 ? ea0 : ea0 + m * 16;
             n = __builtin_amdgcn_readfirstlane(wave == 1 ? m : n_steps - m);
             constexpr int PADV = mfsgd_pad_helper(LG);
-            asm volatile(UB_HELPER_TEXT UB_HELPER_OPS);
+            asm volatile(MFSGD_SOLO_HELPER_ASM_TEXT MFSGD_SOLO_HELPER_OPERANDS);
         }
         if (spins == 0 && lane == 0) cyc[2] = 1;
     }
@@ -177,11 +164,7 @@ int main() {
     const float lr = 0.01f, c = 1.0f - 0.01f * 0.05f;
     // steps visit the p rows in a scrambled order
     std::vector<int> prow(NSTEP);
-#ifdef CONTIG
-    for (int t = 0; t < NSTEP; ++t) prow[t] = t;
-#else
     for (int t = 0; t < NSTEP; ++t) prow[t] = (t * 7) % NSTEP;
-#endif
     std::vector<float> rr(NSTEP);
     std::vector<uint32_t> ent((NSTEP + 2) * 4, 0);
     auto slots = [&](int pr) { return (uint32_t)(pr * LG) | ((uint32_t)(NSTEP * LG) << 16); };
