@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MFSGD_ABI_VERSION 2
+#define MFSGD_ABI_VERSION 3 /* 3 (round 3): + mfsgd_part_settle, mfsgd_dsgd_plan_ex, mfsgd_dsgd_stats; solo-record word order in the debug arrays */
 
 typedef enum mfsgd_status {
     MFSGD_OK = 0,

@@ -23,7 +23,7 @@ def test_exports_every_declared_symbol(mf):
     from mfsgd_amd import _lib
 
     assert declared == set(_lib.SIGNATURES), "ctypes binding out of sync with mfsgd.h"
-    assert lib.mfsgd_abi_version() == 2
+    assert lib.mfsgd_abi_version() == 3
 
 
 def test_create_validation(mf):
