@@ -238,6 +238,49 @@ int fetch_sorted32_cb(void* vctx, uint32_t* sorted) {
     return 0;
 }
 
+// out[dst[x] + y] = sorted[lo[x] + y], y < len[x]: one workgroup per range
+__global__ void __launch_bounds__(256) gather_ranges_kernel(const unsigned* __restrict__ sorted, const long long* __restrict__ lo,
+                                                            const long long* __restrict__ len, const long long* __restrict__ dst,
+                                                            unsigned* __restrict__ out) {
+    const long long a = lo[blockIdx.x], n = len[blockIdx.x], d = dst[blockIdx.x];
+    for (long long y = threadIdx.x; y < n; y += 256) out[d + y] = sorted[a + y];
+}
+
+int fetch_sorted_ranges_cb(void* vctx, int64_t n_ranges, const int64_t* lo, const int64_t* len, uint32_t* out) {
+    Ctx* c = static_cast<Ctx*>(vctx);
+    if (!c->d_sorted || n_ranges < 0) return -1;
+    if (n_ranges == 0) return 0;
+    std::vector<long long> dst((size_t)n_ranges);
+    long long total = 0;
+    for (int64_t x = 0; x < n_ranges; ++x) {
+        if (lo[x] < 0 || len[x] < 0 || lo[x] + len[x] > c->n) return -1;
+        dst[(size_t)x] = total;
+        total += len[x];
+    }
+    if (total == 0) return 0;
+    long long *d_lo = nullptr, *d_len = nullptr, *d_dst = nullptr;
+    unsigned* d_out = nullptr;
+    int rc = -1;
+    static_assert(sizeof(long long) == sizeof(int64_t), "ranges are uploaded as they are");
+    ING_CHK(hipMalloc(&d_lo, 8 * (size_t)n_ranges));
+    ING_CHK(hipMalloc(&d_len, 8 * (size_t)n_ranges));
+    ING_CHK(hipMalloc(&d_dst, 8 * (size_t)n_ranges));
+    ING_CHK(hipMalloc(&d_out, 4 * (size_t)total));
+    ING_CHK(hipMemcpy(d_lo, lo, 8 * (size_t)n_ranges, hipMemcpyHostToDevice));
+    ING_CHK(hipMemcpy(d_len, len, 8 * (size_t)n_ranges, hipMemcpyHostToDevice));
+    ING_CHK(hipMemcpy(d_dst, dst.data(), 8 * (size_t)n_ranges, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(gather_ranges_kernel, dim3((unsigned)n_ranges), dim3(256), 0, 0, c->d_sorted, d_lo, d_len, d_dst, d_out);
+    ING_CHK(hipGetLastError());
+    ING_CHK(hipMemcpy(out, d_out, 4 * (size_t)total, hipMemcpyDeviceToHost));
+    rc = 0;
+fail:
+    if (d_lo) (void)hipFree(d_lo);
+    if (d_len) (void)hipFree(d_len);
+    if (d_dst) (void)hipFree(d_dst);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
 int bucket_dev_cb(void* vctx, const int32_t* u, const int32_t* i, int64_t n, const int32_t* ubin, const int32_t* ibin,
                   int32_t U, int32_t I, int B, int W, int giants, int64_t* bptr) {
     Ctx* c = static_cast<Ctx*>(vctx);
@@ -546,7 +589,7 @@ int download_cb(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* en
     return 0;
 }
 
-const DeviceIngestExt kExt = {bucket_dev_cb, fetch_sorted_cb, fetch_sorted32_cb, pack_count_cb, pack_emit_cb, pack_emit_mixed_cb,
+const DeviceIngestExt kExt = {bucket_dev_cb, fetch_sorted_cb, fetch_sorted32_cb, fetch_sorted_ranges_cb, pack_count_cb, pack_emit_cb, pack_emit_mixed_cb,
                               pack_count_parts_cb, pack_emit_parts_cb, download_cb};
 
 }  // namespace

@@ -73,6 +73,9 @@ struct DeviceIngestExt {
     // the sorted indices after bucket_dev, for the host packer (fallback)
     int (*fetch_sorted)(void* ctx, int64_t* sorted) = nullptr;
     int (*fetch_sorted32)(void* ctx, uint32_t* sorted) = nullptr;  // the same, as the 32-bit indices the device holds
+    // [r3] ... and only `n_ranges` pieces of them -- positions [lo[x], lo[x] + len[x]) of the bucket order, concatenated
+    // into `out` (sum of len entries): the cells whose chunks the host has to decide (a gather on the device, ONE copy)
+    int (*fetch_sorted_ranges)(void* ctx, int64_t n_ranges, const int64_t* lo, const int64_t* len, uint32_t* out) = nullptr;
     // COUNT pass: 0 = done (info: B*B, subs: B*B*W*W), 1 = this rating set is outside what the kernel
     // handles (nothing produced), -1 = a HIP call failed
     int (*pack_count)(void* ctx, const PackRequest& req, std::vector<PackCellInfo>& info, std::vector<SubDesc>& subs) = nullptr;

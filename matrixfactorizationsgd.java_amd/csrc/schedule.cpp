@@ -499,6 +499,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     };
     std::vector<int64_t> sorted;
     std::vector<uint32_t> sorted32;  // the same thing when it was fetched from the device packer's context
+    bool want_dev_chunks = false;    // mixed mode with the chunks packed on the device: the bucket order stays there
     const DeviceIngestExt* ext = (on_device && prm.device_pack && prm.ingest->ext && prm.ingest->ext->bucket_dev &&
                                   prm.ingest->ext->pack_count && prm.ingest->ext->pack_emit && n > 0)
                                      ? prm.ingest->ext
@@ -666,13 +667,18 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
             return 0;
         }
-        // the host packer needs the bucket order on this side (32-bit, as the device holds it)
-        sorted32.resize((size_t)n);
-        if (!ext->fetch_sorted32 || ext->fetch_sorted32(prm.ingest->ctx, sorted32.data()) != 0) {
-            err = "build_schedule: could not fetch the bucket order from the device";
-            return -1;
-        }
         if (rc != 1) have_info = false;
+        // the host packer needs the bucket order on this side (32-bit, as the device holds it) -- unless the device packs
+        // the chunks too ([r3]): then only the cells that are cut come here, once it is known which
+        want_dev_chunks = have_info && ext->pack_count_parts && ext->pack_emit_parts && ext->fetch_sorted_ranges &&
+                          !std::getenv("MFSGD_HOST_CHUNKS");
+        if (!want_dev_chunks) {
+            sorted32.resize((size_t)n);
+            if (!ext->fetch_sorted32 || ext->fetch_sorted32(prm.ingest->ctx, sorted32.data()) != 0) {
+                err = "build_schedule: could not fetch the bucket order from the device";
+                return -1;
+            }
+        }
         if (trace)
             std::fprintf(stderr, "[schedule]   device pack %s: %s%s\n", rc == 1 ? "declined" : "FAILED", why,
                          have_info ? " -> mixed mode: the device keeps the cells that fit, the host packs the rest" : "");
@@ -866,22 +872,22 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     // [r3] Mixed mode with the chunks packed on the device as well (pack_count_parts / pack_emit_parts): the host only
     // DECIDES the cuts -- from the cells' ids -- and asks the device for the size of every candidate chunk.
     // MFSGD_HOST_CHUNKS=1: round 2's mixed mode (the host packs and chunks what the device declines; A/B measurements).
-    const bool dev_chunks = have_info && ext && ext->pack_count_parts && ext->pack_emit_parts && !sorted32.empty() &&
-                            !std::getenv("MFSGD_HOST_CHUNKS");
+    const bool dev_chunks = have_info && ext && want_dev_chunks;
     // Phase 1: every cell as a single chunk, unless it cannot possibly fit.
     std::vector<CellOut> co((size_t)ncell);
     std::vector<uint8_t> oversize((size_t)ncell, 0);
     {
         std::atomic<int64_t> next_cell{0};
+        // cells are claimed in batches: in mixed mode most of them only copy five numbers, and one atomic per cell
+        // (590 K of them at the Netflix shape, contended by 16 threads) cost more than the work
+        const int64_t batch = have_info ? 256 : 1;
         run_parallel([&](Scratch& sc, std::vector<RawRat>& sel) {
             for (;;) {
-                const int64_t c = next_cell.fetch_add(1);
-                if (c >= ncell) break;
+                const int64_t c0 = next_cell.fetch_add(batch);
+                if (c0 >= ncell) break;
+                for (int64_t c = c0; c < std::min(ncell, c0 + batch); ++c) {
                 CellOut& o = co[(size_t)c];
-                if (bptr[(size_t)(c * WW)] == bptr[(size_t)((c + 1) * WW)]) {
-                    o.subs.assign((size_t)WW, SubDesc{0, 0});
-                    continue;
-                }
+                if (bptr[(size_t)(c * WW)] == bptr[(size_t)((c + 1) * WW)]) continue;  // (an empty cell: place() writes zeros)
                 if (have_info) {
                     // mixed mode: a cell the device packed as one chunk stays there (only its sizes come here)
                     const PackCellInfo& ci = info[(size_t)c];
@@ -921,6 +927,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     o.ni = (uint32_t)ni;
                     o.n_order = (int64_t)sel.size();
                     oversize[(size_t)c] = 1;
+                }
                 }
             }
         });
@@ -1043,23 +1050,37 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         std::vector<std::vector<Leaf>> leaves((size_t)todo.size());
         std::vector<Part> level;
         level.reserve(todo.size());
+        // the bucket order of the cells to be cut, and of those only
+        std::vector<int64_t> r_lo(todo.size()), r_len(todo.size()), r_at(todo.size() + 1, 0);
+        for (size_t x = 0; x < todo.size(); ++x) {
+            const int64_t c = todo[x];
+            r_lo[x] = bptr[(size_t)(c * WW)];
+            r_len[x] = bptr[(size_t)((c + 1) * WW)] - r_lo[x];
+            r_at[x + 1] = r_at[x] + r_len[x];
+        }
+        std::vector<uint32_t> cut_sorted((size_t)r_at[todo.size()]);
+        if (ext->fetch_sorted_ranges(prm.ingest->ctx, (int64_t)todo.size(), r_lo.data(), r_len.data(), cut_sorted.data()) != 0) {
+            err = "build_schedule: could not fetch the bucket order of the cells to be cut from the device";
+            return -1;
+        }
+        lap("  bucket order of the cut cells to the host");
         for (size_t x = 0; x < todo.size(); ++x) {
             const int64_t c = todo[x];
             Part p;
             p.cell = (int64_t)x;
             p.path = 0;
             p.depth = 0;
-            const int64_t lo = bptr[(size_t)(c * WW)], hi = bptr[(size_t)((c + 1) * WW)];
-            p.idx.resize((size_t)(hi - lo));
+            const int64_t lo = r_lo[x], hi = lo + r_len[x];
+            p.idx.assign(cut_sorted.begin() + (long)r_at[x], cut_sorted.begin() + (long)r_at[x + 1]);
             p.sb.resize((size_t)(hi - lo));
             int sbi = 0;
             for (int64_t y = lo; y < hi; ++y) {
                 while (bptr[(size_t)(c * WW + sbi + 1)] <= y) ++sbi;
-                p.idx[(size_t)(y - lo)] = sorted32[(size_t)y];
                 p.sb[(size_t)(y - lo)] = (uint16_t)sbi;
             }
             level.push_back(std::move(p));
         }
+        std::vector<uint32_t>().swap(cut_sorted);
         bool root = true;
         while (!level.empty() && !failed.load()) {
             // 1. distinct rows of every part; whole cells (the roots) are known not to fit: they are cut unseen
@@ -1427,10 +1448,13 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         std::vector<uint32_t> p_idx, p_ro, p_eo;
         std::vector<int64_t> p_cptr, p_oo;
         std::vector<int64_t> part_of_desc((size_t)n_descs, -1);
+        std::vector<int64_t> p_desc, p_at;
+        int64_t p_total = 0;
         if (n_dev_parts > 0) {
+            p_desc.reserve((size_t)n_dev_parts);
+            p_at.reserve((size_t)n_dev_parts);
             p_ro.reserve((size_t)n_dev_parts);
             p_eo.reserve((size_t)n_dev_parts);
-            p_cptr.reserve((size_t)(n_dev_parts * WW) + 1);
         }
         for (int64_t x = 0; x < n_descs; ++x) {
             const CellOut& o = *by_desc[(size_t)x];
@@ -1444,12 +1468,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 part_of_desc[(size_t)x] = (int64_t)p_ro.size();
                 p_ro.push_back(d.row_off);
                 p_eo.push_back(d.ent_off);
-                size_t at = 0;
-                for (int sbi = 0; sbi < WW; ++sbi) {
-                    p_cptr.push_back((int64_t)(p_idx.size() + at));
-                    while (at < o.part_sb.size() && o.part_sb[at] == (uint16_t)sbi) ++at;
-                }
-                p_idx.insert(p_idx.end(), o.part_idx.begin(), o.part_idx.end());
+                p_desc.push_back(x);
+                p_at.push_back(p_total);  // where its ratings start in the concatenated list (filled in parallel below)
+                p_total += (int64_t)o.part_idx.size();
                 continue;
             }
             if (!o.rows.empty()) {
@@ -1461,7 +1482,33 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 mp.entries.insert(mp.entries.end(), o.entries.begin(), o.entries.end());
             }
         }
-        p_cptr.push_back((int64_t)p_idx.size());
+        if (n_dev_parts > 0) {
+            // the chunks' rating lists one after another, and their W*W sub-cell starts: independent per chunk
+            p_idx.resize((size_t)p_total);
+            p_cptr.assign(p_ro.size() * (size_t)WW + 1, 0);
+            std::atomic<size_t> nx{0};
+            auto fill = [&]() {
+                for (;;) {
+                    const size_t y0 = nx.fetch_add(64);
+                    if (y0 >= p_desc.size()) break;
+                    for (size_t y = y0; y < std::min(p_desc.size(), y0 + 64); ++y) {
+                        const CellOut& o = *by_desc[(size_t)p_desc[y]];
+                        const int64_t base = p_at[y];
+                        std::memcpy(&p_idx[(size_t)base], o.part_idx.data(), o.part_idx.size() * sizeof(uint32_t));
+                        size_t at = 0;
+                        for (int sbi = 0; sbi < WW; ++sbi) {
+                            p_cptr[y * (size_t)WW + (size_t)sbi] = base + (int64_t)at;
+                            while (at < o.part_sb.size() && o.part_sb[at] == (uint16_t)sbi) ++at;
+                        }
+                    }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nthreads; ++t) th.emplace_back(fill);
+            fill();
+            for (auto& t : th) t.join();
+            p_cptr[p_ro.size() * (size_t)WW] = p_total;
+        }
         p_oo.assign(p_ro.size(), 0);
         for (int64_t x = 0; x < ncell; ++x) {
             const int64_t rd = x / B, b = x % B;
