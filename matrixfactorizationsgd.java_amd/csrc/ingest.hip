@@ -36,6 +36,11 @@ struct Ctx {
     PackArgs args{};                 // as launched for COUNT; EMIT reuses it
     int64_t n_cells = 0;
     int rows_full = 0;               // the row capacity no cell (or part of one) can exceed
+    // one-pass mode: what the COUNT pass already wrote
+    uint32_t* d_srows = nullptr;     // scratch rows (2 per rating)
+    Entry* d_sent = nullptr;         // scratch entries (worst-case strides)
+    long long* d_order = nullptr;    // the canonical order, final
+    long long* d_ord_off = nullptr;
 };
 
 #define ING_CHK(call)                      \
@@ -47,9 +52,14 @@ struct Ctx {
     } while (0)
 
 void drop_pack_state(Ctx* c) {
-    void* ptrs[] = {c->d_sorted, c->d_bptr, c->d_r, c->d_orig, c->d_urank, c->d_irank, c->d_info, c->d_subs};
+    void* ptrs[] = {c->d_sorted, c->d_bptr, c->d_r, c->d_orig, c->d_urank, c->d_irank, c->d_info, c->d_subs,
+                    c->d_srows, c->d_sent, c->d_order, c->d_ord_off};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    c->d_srows = nullptr;
+    c->d_sent = nullptr;
+    c->d_order = nullptr;
+    c->d_ord_off = nullptr;
     c->d_sorted = nullptr;
     c->d_bptr = nullptr;
     c->d_r = nullptr;
@@ -367,6 +377,34 @@ int pack_count_cb(void* vctx, const PackRequest& q, std::vector<PackCellInfo>& i
     a.info = c->d_info;
     a.subs = c->d_subs;
     a.emit = 0;
+    if (q.ord_off && !std::getenv("MFSGD_PACK_TWICE")) {  // (the variable: A/B measurements)
+        // one-pass mode: scratch for rows and entries, the order array itself; if any of it does not fit, count only
+        // (nor when the scratch would take more than a third of what is free: the final arrays come after it)
+        const size_t steps = pack_scratch_steps(q.n, n_cells, q.W);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        const size_t need = sizeof(Entry) * steps * (size_t)q.G + 16 * (size_t)std::max<int64_t>(q.n, 1);
+        if (need <= free_b / 3 && hipMalloc(&c->d_srows, 4 * (2 * (size_t)std::max<int64_t>(q.n, 1))) == hipSuccess &&
+            hipMalloc(&c->d_sent, sizeof(Entry) * steps * (size_t)q.G) == hipSuccess &&
+            hipMalloc(&c->d_order, 8 * (size_t)std::max<int64_t>(q.n, 1)) == hipSuccess &&
+            hipMalloc(&c->d_ord_off, 8 * (size_t)n_cells) == hipSuccess &&
+            hipMemcpy(c->d_ord_off, q.ord_off, 8 * (size_t)n_cells, hipMemcpyHostToDevice) == hipSuccess) {
+            a.emit = 2;
+            a.rows = c->d_srows;
+            a.entries = c->d_sent;
+            a.order = c->d_order;
+            a.ord_off = c->d_ord_off;
+        } else {
+            (void)hipGetLastError();
+            void* ptrs[] = {c->d_srows, c->d_sent, c->d_order, c->d_ord_off};
+            for (void* p : ptrs)
+                if (p) (void)hipFree(p);
+            c->d_srows = nullptr;
+            c->d_sent = nullptr;
+            c->d_order = nullptr;
+            c->d_ord_off = nullptr;
+        }
+    }
     info.resize((size_t)n_cells);
     subs.resize((size_t)(n_cells * WW));
     for (;;) {
@@ -418,6 +456,10 @@ bool upload_parts(Ctx* c, int64_t n_parts, const uint32_t* sorted, int64_t n_sor
         return false;
     }
     a = c->args;
+    a.rows = nullptr;  // (a COUNT pass proper: the cells' one-pass scratch is not the parts')
+    a.entries = nullptr;
+    a.order = nullptr;
+    a.ord_off = nullptr;
     a.max_rows = c->rows_full;  // a part can hold any number of rows a cell can
     a.sorted = pl.d_sorted;
     a.bptr = pl.d_cptr;
@@ -463,6 +505,7 @@ int emit_common(Ctx* c, const uint32_t* row_off, const uint32_t* ent_off, const 
     Entry* d_ent = nullptr;
     void* staged[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const size_t nc = (size_t)c->n_cells;
+    const bool one_pass = c->d_sent != nullptr;  // the COUNT pass wrote what it packed: move it, do not pack again
     std::vector<long long> oo(ord_off, ord_off + nc);
     auto stage = [&](int slot, const void* p, size_t bytes) -> bool {
         if (bytes == 0) return true;
@@ -477,15 +520,25 @@ int emit_common(Ctx* c, const uint32_t* row_off, const uint32_t* ent_off, const 
     ING_CHK(hipMalloc(&d_rows, 4 * (size_t)(n_rows + 4)));
     ING_CHK(hipMemset(d_rows + n_rows, 0, 16));  // the staging DMA reads whole 16-byte units
     ING_CHK(hipMalloc(&d_ent, sizeof(Entry) * (size_t)std::max<int64_t>(n_steps * a.G, 1)));
-    ING_CHK(hipMalloc(&d_order, 8 * (size_t)std::max<int64_t>(c->n, 1)));
-    a.emit = 1;
+    if (one_pass) {
+        d_order = c->d_order;  // written by the COUNT pass, at its final place
+        c->d_order = nullptr;
+    } else {
+        ING_CHK(hipMalloc(&d_order, 8 * (size_t)std::max<int64_t>(c->n, 1)));
+    }
     a.row_off = d_ro;
     a.ent_off = d_eo;
     a.ord_off = d_oo;
     a.rows = d_rows;
     a.entries = d_ent;
     a.order = d_order;
-    ING_CHK(launch_pack(a, c->n_cells, (hipStream_t)0));
+    if (one_pass) {
+        a.emit = 2;
+        ING_CHK(launch_compact(a, c->n_cells, c->d_srows, c->d_sent, (hipStream_t)0));
+    } else {
+        a.emit = 1;
+        ING_CHK(launch_pack(a, c->n_cells, (hipStream_t)0));
+    }
     if (parts && parts->n_parts > 0) {
         // the chunks of the cells that were cut: COUNT over the final list (the EMIT pass reads the sub-cell table the
         // COUNT pass of the SAME list left on the device), then EMIT at the caller's offsets into the same arrays

@@ -45,6 +45,11 @@ struct PackRequest {
     float lr = 0.f, c = 0.f;
     bool solo_ok = false;
     int64_t max_cell_nnz = 0;       // from bptr
+    // [r3] host, per cell, or null: where the cell's ratings start in the canonical order (it follows from the bucket
+    // starts alone).  With it the COUNT pass also WRITES what it packs -- rows and entries into scratch arrays at
+    // worst-case offsets, the order at its final place -- and the emit calls below only move the cells that are kept to
+    // their offsets: the packing runs once.  Without it (or when the scratch does not fit) they pack a second time.
+    const int64_t* ord_off = nullptr;
 };
 // Buffers a successful emit() leaves on the device; the receiver frees them with `release`.
 struct DevicePacked {

@@ -31,6 +31,10 @@ namespace mfsgd {
 namespace {
 
 constexpr int kWaves = 4;  // waves per workgroup
+// one-pass mode: a sub-cell of n ratings packs into at most 2 n + kPackSlack steps -- a general or run step can come out
+// empty when every rating left is blocked by the step before it, but never two in a row; the slack is a run's padding
+// step, the idle steps in front of a solo run, its header and terminator records
+constexpr int kPackSlack = 3 + kSoloPad;
 
 struct WaveState {
     int* remdeg;         // per row slot: ratings left on the row in the current list (also the degree counter)
@@ -107,21 +111,21 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
     int* sub_info = reinterpret_cast<int*>(wbase + (size_t)kWaves * wave_bytes);  // [x][0..3] = ns, nr, nsolo, units
     int* misc = sub_info + WW * 4;                                                  // [0] status, [1] nu, [2] ni
 
-    if (a.emit && a.row_off[cell] == 0xFFFFFFFFu) return;  // mixed build: the host packed this cell
+    if (a.emit == 1 && a.row_off[cell] == 0xFFFFFFFFu) return;  // mixed build: this cell is cut (its chunks come as parts)
     const long long lo = a.bptr[cell * WW], hi = a.bptr[(cell + 1) * WW];
     const int m = (int)(hi - lo);
     PackCellInfo info{};
     if (tid == 0) misc[0] = 0;
     if (m == 0) {
-        if (!a.emit && tid == 0) {
+        if (a.emit != 1 && tid == 0) {
             a.info[cell] = info;
         }
-        if (!a.emit)
+        if (a.emit != 1)
             for (int x = tid; x < WW; x += 64 * kWaves) a.subs[cell * WW + x] = SubDesc{0u, 0u};
         return;
     }
     if (m > M) {
-        if (!a.emit && tid == 0) {
+        if (a.emit != 1 && tid == 0) {
             info.status = 1;
             a.info[cell] = info;
         }
@@ -165,9 +169,14 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
     }
     __syncthreads();
     const int nu = misc[1], ni = misc[2], nrows = nu + ni;
+    // where this pass writes: the EMIT pass (emit == 1) at the offsets the host derived from a COUNT pass; the one-pass
+    // mode (emit == 2, [r3]) into SCRATCH arrays at worst-case offsets known from the bucket starts alone -- at most two
+    // rows per rating, and a sub-cell of n ratings packs into at most 2 n + kPackSlack steps -- which compact_kernel moves
+    // to their final places once the host has the sizes: the packing itself runs once
+    const size_t row_base = a.emit == 1 ? (size_t)a.row_off[cell] : 2 * (size_t)lo;
     bool bad = nrows > R || (long long)(nrows + 2 * G) * L > 32767 || nu > 0xFFFF || ni > 0xFFFF;
     if (bad) {
-        if (!a.emit && tid == 0) {
+        if (a.emit != 1 && tid == 0) {
             info.status = nrows > R ? 2 : 1;  // 2: more rows than this launch's LDS arrays hold (a retry with more may do)
             info.nu = (unsigned)nu;
             info.ni = (unsigned)ni;
@@ -183,15 +192,16 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
         rat_q[x] = (unsigned short)qs;
         if (a.emit) {  // row ids, users then items, ascending id = ascending rank (every occurrence writes the same value)
             const unsigned j = rat_i[x];
-            a.rows[a.row_off[cell] + ps] = (unsigned)a.u[j];
-            a.rows[a.row_off[cell] + qs] = (unsigned)a.i[j];
+            a.rows[row_base + (size_t)ps] = (unsigned)a.u[j];
+            a.rows[row_base + (size_t)qs] = (unsigned)a.i[j];
         }
     }
     __syncthreads();
 
     // ---- sub-cells, dealt to the waves -----------------------------------------------------------
     const float lr = a.lr, cdecay = a.c;
-    const unsigned ent_base = a.emit ? a.ent_off[cell] : 0u;  // first step of the cell
+    const size_t ent_base = a.emit == 1 ? (size_t)a.ent_off[cell]
+                            : 2 * (size_t)lo + (size_t)cell * (size_t)(WW * kPackSlack + 2);  // first step of the cell
     const long long ord_base = a.emit ? a.ord_off[cell] : 0;
     auto put_entry = [&](unsigned step, int g, unsigned slots, float r, float ce) {
         Entry e;
@@ -199,7 +209,7 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
         e.r = r;
         e.lrr = lr * r;
         e.ce = ce;
-        a.entries[((size_t)ent_base + step) * G + g] = e;
+        a.entries[(ent_base + step) * G + g] = e;
     };
     auto idle_general = [&](unsigned step) {  // an all-idle general step (every lane helps)
         for (int g = lane; g < G; g += 64) put_entry(step, g, enc_slots(nrows + 2 * g, nrows + 2 * g + 1, false, L), 0.0f, cdecay);
@@ -213,7 +223,7 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
         unsigned stepcur = 0;
         long long ord_at = 0;
         if (a.emit) {
-            stepcur = a.subs[cell * WW + x].off & 0xFFFFu;
+            stepcur = a.emit == 1 ? (a.subs[cell * WW + x].off & 0xFFFFu) : (unsigned)(2 * slo + x * kPackSlack);
             ord_at = ord_base + slo;
         }
         if (nsub > 0) {
@@ -599,7 +609,7 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
             for (int w = 0; w < W; ++w) {
                 const int* si = sub_info + (s * W + w) * 4;
                 if (stepcur > 0xFFFFu) fail = true;
-                if (!a.emit) a.subs[cell * WW + s * W + w] = SubDesc{stepcur | ((unsigned)si[2] << 16), (unsigned)si[0] | ((unsigned)si[1] << 16)};
+                if (a.emit != 1) a.subs[cell * WW + s * W + w] = SubDesc{stepcur | ((unsigned)si[2] << 16), (unsigned)si[0] | ((unsigned)si[1] << 16)};
                 stepcur += (unsigned)(si[0] + si[1] + si[3]);
                 if (si[1] > 0 || si[2] > 0) has_run = true;
                 const unsigned cost = (unsigned)(si[0] + si[1] + si[2] * 3 / 4);
@@ -607,7 +617,7 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
             }
             crit += smax;
         }
-        if (!a.emit) {
+        if (a.emit != 1) {
             info.status = fail ? 1 : 0;
             info.nu = (unsigned)nu;
             info.ni = (unsigned)ni;
@@ -619,12 +629,56 @@ __global__ void __launch_bounds__(64 * kWaves) pack_kernel(const PackArgs a) {
         misc[3] = (int)stepcur;
     }
     __syncthreads();
-    if (a.emit && wave == 0) {
+    if (a.emit == 1 && wave == 0) {  // (one-pass mode: compact_kernel writes them)
         const unsigned stepcur = (unsigned)misc[3];
         idle_general(stepcur);
         idle_general(stepcur + 1);
     }
 }
+
+// One-pass mode, second half: the cells whose row_off is not 0xFFFFFFFF move from the scratch arrays (worst-case offsets,
+// see pack_kernel) to their final places; the two trailing idle steps of a cell are written here.  One workgroup per cell.
+__global__ void __launch_bounds__(256) compact_kernel(const PackArgs a, const uint32_t* __restrict__ srows, const Entry* __restrict__ sent) {
+    const long long cell = blockIdx.x;
+    if (a.row_off[cell] == 0xFFFFFFFFu) return;
+    const PackCellInfo ci = a.info[cell];
+    if (ci.n_steps == 0) return;
+    const int W = a.W, WW = W * W, G = a.G, L = a.L;
+    const long long lo = a.bptr[cell * WW];
+    const int nrows = (int)(ci.nu + ci.ni);
+    const size_t row_src = 2 * (size_t)lo, row_dst = (size_t)a.row_off[cell];
+    for (int x = threadIdx.x; x < nrows; x += 256) a.rows[row_dst + (size_t)x] = srows[row_src + (size_t)x];
+    const size_t ent_src = 2 * (size_t)lo + (size_t)cell * (size_t)(WW * kPackSlack + 2), ent_dst = (size_t)a.ent_off[cell];
+    const uint4* src4 = reinterpret_cast<const uint4*>(sent);
+    uint4* dst4 = reinterpret_cast<uint4*>(a.entries);
+    for (int x = 0; x < WW; ++x) {
+        const SubDesc sd = a.subs[cell * WW + x];
+        const int nsolo = (int)(sd.off >> 16), ns = (int)(sd.n & 0xFFFFu), nr = (int)(sd.n >> 16);
+        const int units = nsolo > 0 ? (nsolo + 2 + G - 1) / G + kSoloPad : 0;
+        const long long cnt = (long long)(ns + nr + units) * G;
+        const size_t s0 = (ent_src + 2 * (size_t)(a.bptr[cell * WW + x] - lo) + (size_t)x * kPackSlack) * (size_t)G;
+        const size_t d0 = (ent_dst + (size_t)(sd.off & 0xFFFFu)) * (size_t)G;
+        for (long long y = threadIdx.x; y < cnt; y += 256) dst4[d0 + (size_t)y] = src4[s0 + (size_t)y];
+    }
+    if ((int)threadIdx.x < 2 * G) {
+        const int step = (int)ci.n_steps - 2 + (int)threadIdx.x / G, g = (int)threadIdx.x % G;
+        Entry e;
+        e.slots = enc_slots(nrows + 2 * g, nrows + 2 * g + 1, false, L);
+        e.r = 0.0f;
+        e.lrr = a.lr * 0.0f;
+        e.ce = a.c;
+        a.entries[(ent_dst + (size_t)step) * G + g] = e;
+    }
+}
+
+hipError_t launch_compact(const PackArgs& a, long long n_cells, const uint32_t* srows, const Entry* sent, hipStream_t st) {
+    if (n_cells <= 0) return hipSuccess;
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)n_cells), dim3(256), 0, st, a, srows, sent);
+    return hipGetLastError();
+}
+
+// steps / rows of the scratch arrays of the one-pass mode for n ratings in n_cells cells of W*W sub-cells
+size_t pack_scratch_steps(long long n, long long n_cells, int W) { return 2 * (size_t)n + (size_t)n_cells * (size_t)(W * W * kPackSlack + 2); }
 
 // dst[seg.dst + x] = src[seg.src + x] for x < seg.n, elements of `elem` bytes (a multiple of 4): one workgroup
 // per segment.  Places the pieces the host packed in a mixed build.

@@ -24,7 +24,9 @@ struct PackArgs {
     int solo_ok;
     int max_m, max_rows;     // capacities of the kernel's LDS arrays (ratings per cell, rows per cell)
     int u_words, i_words;    // bitmap words: ceil(max rank + 1 / 32)
-    int emit;                // 0: COUNT pass, 1: EMIT pass
+    int emit;                // 0: COUNT pass, 1: EMIT pass, 2: one pass -- COUNT outputs AND rows / entries into scratch arrays at
+                             //    worst-case offsets (rows, entries point at the scratch), order at its final place; launch_compact
+                             //    then moves the cells that are kept to their offsets
     PackCellInfo* info;      // COUNT out: per cell
     SubDesc* subs;           // COUNT out / EMIT in: per cell W*W
     const uint32_t* row_off; // EMIT in: per cell
@@ -40,5 +42,8 @@ struct MixedSegment;
 hipError_t launch_scatter(void* dst, const void* src, const MixedSegment* segs, long long n_segs, int elem_bytes, hipStream_t st);
 size_t pack_lds_bytes(const PackArgs& a);
 hipError_t launch_pack(const PackArgs& a, long long n_cells, hipStream_t st);
+// one-pass mode: a.rows / a.entries / a.row_off / a.ent_off FINAL, a.info / a.subs from the pass, scratch arrays as written by it
+hipError_t launch_compact(const PackArgs& a, long long n_cells, const uint32_t* srows, const Entry* sent, hipStream_t st);
+size_t pack_scratch_steps(long long n, long long n_cells, int W);
 
 }  // namespace mfsgd
