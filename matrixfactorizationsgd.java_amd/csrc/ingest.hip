@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "ingest.hpp"
+#include "hugepages.hpp"
 #include "pack.hpp"
 
 namespace mfsgd {
@@ -405,7 +406,9 @@ int pack_count_cb(void* vctx, const PackRequest& q, std::vector<PackCellInfo>& i
             c->d_ord_off = nullptr;
         }
     }
+    reserve_huge(info, (size_t)n_cells);
     info.resize((size_t)n_cells);
+    reserve_huge(subs, (size_t)(n_cells * WW));
     subs.resize((size_t)(n_cells * WW));
     for (;;) {
         ING_CHK(launch_pack(a, n_cells, (hipStream_t)0));

@@ -1,5 +1,6 @@
 // schedule.cpp -- see schedule.hpp.  Host only; no HIP calls.
 #include "schedule.hpp"
+#include "hugepages.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -11,6 +12,7 @@
 #include <exception>
 #include <functional>
 #include <iterator>
+#include <memory>
 #include <numeric>
 #include <queue>
 #include <mutex>
@@ -85,16 +87,30 @@ int lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>&
                deg[(size_t)idx[(size_t)giants]] >= std::max(mean, giant_min))
             ++giants;
     }
-    using Item = std::pair<int64_t, int32_t>;  // (load, bin): smallest load, then smallest bin
-    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
+    // (load, bin): smallest load, then smallest bin.  A binary min-heap whose top is replaced in place -- one
+    // sift-down per row instead of priority_queue's pop + push; the order of equal keys cannot matter, the keys
+    // (load, bin) are distinct
+    using Item = std::pair<int64_t, int32_t>;
+    std::vector<Item> heap;
+    heap.reserve((size_t)nbins);
     for (int32_t b = 0; b < nbins; ++b)
-        if (!(b >= stride && stride > 0 && b % stride < giants)) heap.push({0, b});  // not a giant's tile-mate
+        if (!(b >= stride && stride > 0 && b % stride < giants)) heap.push_back({0, b});  // not a giant's tile-mate
+    // (all loads 0, bins ascending: already a heap)
+    const size_t hn = heap.size();
     for (int32_t x : idx) {
-        Item t = heap.top();
-        heap.pop();
+        Item t = heap[0];
         bin[(size_t)x] = t.second;
         t.first += deg[(size_t)x];
-        heap.push(t);
+        size_t at = 0;
+        for (;;) {
+            size_t ch = 2 * at + 1;
+            if (ch >= hn) break;
+            if (ch + 1 < hn && heap[ch + 1] < heap[ch]) ++ch;
+            if (!(heap[ch] < t)) break;
+            heap[at] = heap[ch];
+            at = ch;
+        }
+        heap[at] = t;
     }
     return giants;
 }
@@ -131,23 +147,38 @@ struct RawRat {
     uint16_t sb;  // sub-cell inside the cell: sub-round * W + wave
 };
 
-struct CellOut {
+// What a cell's (or chunk's) packer wrote, when it is in host memory; boxed, because most cells of a large rating set
+// are packed on the device and hold none of it -- 590 K records of six empty vectors each were 118 MB to fault in and
+// to give back at the Netflix shape.
+struct CellArrays {
     std::vector<uint32_t> rows;
     std::vector<Entry> entries;
     std::vector<SubDesc> subs;
     std::vector<int64_t> order;
+    // [r3] a CHUNK the device packs (a part of a cell that was cut): its ratings as indices into the caller's arrays, in
+    // the cell's bucket order, with the sub-cell of each -- the packing kernel takes the list as a cell of its own
+    std::vector<uint32_t> part_idx;
+    std::vector<uint16_t> part_sb;
+};
+
+struct CellOut {
+    std::unique_ptr<CellArrays> arr;
+    CellArrays& a() {
+        if (!arr) arr.reset(new CellArrays);
+        return *arr;
+    }
+    const CellArrays& a() const {
+        static const CellArrays none;
+        return arr ? *arr : none;
+    }
     uint32_t nu = 0, ni = 0, n_steps = 0;
     int64_t crit = 0;
     bool has_run = false;
-    // sizes, valid also when the arrays above are empty because the DEVICE holds (or will write) the data
+    // sizes, valid also when there are no arrays because the DEVICE holds (or will write) the data
     uint32_t n_rows = 0;
     int64_t n_order = 0;
-    bool dev = false;  // packed by the device packer: rows / entries / order are not here
-    // [r3] a CHUNK the device packs (a part of a cell that was cut): its ratings as indices into the caller's arrays, in
-    // the cell's bucket order, with the sub-cell of each -- the packing kernel takes the list as a cell of its own
-    bool dev_part = false;
-    std::vector<uint32_t> part_idx;
-    std::vector<uint16_t> part_sb;
+    bool dev = false;       // packed by the device packer: rows / entries / order are not here
+    bool dev_part = false;  // a chunk the device packs from part_idx / part_sb
     mutable int64_t desc = -1;  // its chunk descriptor, once placed
 };
 
@@ -503,7 +534,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
 
     // ---- counting sort by (cell, sub-round, wave) ---------------------------
     const int64_t nb = (int64_t)B * B * W * W;
-    std::vector<int64_t> bptr((size_t)nb + 1, 0);
+    std::vector<int64_t> bptr;
+    reserve_huge(bptr, (size_t)nb + 1);
+    bptr.assign((size_t)nb + 1, 0);
     auto bucket_of = [&](int64_t j) -> int64_t {
         const int32_t fu = ubin[(size_t)u[j]], fi = ibin[(size_t)i[j]];
         // (an item with a tile of its own: all its ratings in the cell's first sub-cell -- the tile holds nothing
@@ -711,7 +744,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     auto pack_chunk = [&](const std::vector<RawRat>& sel, CellOut& o, Scratch& sc) -> bool {
         const int64_t m = (int64_t)sel.size();
         o = CellOut{};
-        o.subs.assign((size_t)WW, SubDesc{0, 0});
+        o.a().subs.assign((size_t)WW, SubDesc{0, 0});
         std::vector<uint32_t>& uu = sc.us;
         std::vector<uint32_t>& ii = sc.is;
         uu.resize((size_t)m);
@@ -727,9 +760,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         const int nu = (int)uu.size(), ni = (int)ii.size(), nrows = nu + ni;
         o.nu = (uint32_t)nu;
         o.ni = (uint32_t)ni;
-        o.rows.reserve((size_t)nrows);
-        o.rows.insert(o.rows.end(), uu.begin(), uu.end());
-        o.rows.insert(o.rows.end(), ii.begin(), ii.end());
+        o.a().rows.reserve((size_t)nrows);
+        o.a().rows.insert(o.a().rows.end(), uu.begin(), uu.end());
+        o.a().rows.insert(o.a().rows.end(), ii.begin(), ii.end());
         sc.rats.resize((size_t)m);
         int64_t sub_lo[65];  // first rating of sub-cell x (x = s * W + w), sub_lo[WW] = m
         {
@@ -751,8 +784,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         sc.lastslot.assign((size_t)nrows, (int8_t)-1);
         sc.prevstep.assign((size_t)nrows, 0);
         int32_t tstamp = 1;  // step stamps start at 2 so that t-1 never matches 0
-        o.entries.reserve((size_t)(m + m / 2 + G));
-        o.order.reserve((size_t)m);
+        o.a().entries.reserve((size_t)(m + m / 2 + G));
+        o.a().order.reserve((size_t)m);
         uint32_t stepcur = 0;
         int64_t crit = 0;
         for (int s = 0; s < W; ++s) {
@@ -817,10 +850,10 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     ngen = (int)(std::stable_partition(sub, sub + nnon, [&](const Rat& x) { return !is_run(x); }) - sub);
                 }
                 ++tstamp;  // break stickiness across sub-cells
-                pack_subcell(sub, ngen, G, geo.L, nrows, hy, sc, tstamp, o.entries, o.order, ns);
+                pack_subcell(sub, ngen, G, geo.L, nrows, hy, sc, tstamp, o.a().entries, o.a().order, ns);
                 if (nrun > 0) {
                     ++tstamp;  // the run starts with fresh loads: no hazard against the last general step
-                    pack_run(sub + ngen, nnon - ngen, run_q, nrun, G, geo.L, nrows, hy, sc, tstamp, o.entries, o.order,
+                    pack_run(sub + ngen, nnon - ngen, run_q, nrun, G, geo.L, nrows, hy, sc, tstamp, o.a().entries, o.a().order,
                              nr);
                 }
                 uint32_t nsu = 0;  // step units the solo records occupy
@@ -830,13 +863,13 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     // look-ahead on step-format entries, whatever follows
                     for (int pad = 0; pad < kSoloPad; ++pad)
                         for (int g = 0; g < G; ++g)
-                            o.entries.push_back(make_entry(encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, geo.L), 0.0f, hy.c, hy));
-                    pack_solo(sub + nnon, nsolo, G, geo.L, nrows, hy, o.entries, o.order, nsu);
+                            o.a().entries.push_back(make_entry(encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, geo.L), 0.0f, hy.c, hy));
+                    pack_solo(sub + nnon, nsolo, G, geo.L, nrows, hy, o.a().entries, o.a().order, nsu);
                     nsu += kSoloPad;
                 }
                 if (ns > 0xFFFF || nr > 0xFFFF || nsolo > 0xFFFF || stepcur > 0xFFFF) return false;
                 if (nr > 0 || nsolo > 0) o.has_run = true;
-                o.subs[(size_t)(s * W + w)] = SubDesc{stepcur | ((uint32_t)nsolo << 16), ns | (nr << 16)};
+                o.a().subs[(size_t)(s * W + w)] = SubDesc{stepcur | ((uint32_t)nsolo << 16), ns | (nr << 16)};
                 stepcur += ns + nr + nsu;
                 // a solo step costs about three quarters of a run step (137 against 184 cycles at L = 16)
                 smax = std::max(smax, ns + nr + (uint32_t)(nsolo * 3 / 4));
@@ -846,7 +879,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         // two trailing idle steps: the kernel reads entries t+1 and t+2 ahead
         for (int pad = 0; pad < 2; ++pad)
             for (int g = 0; g < G; ++g)
-                o.entries.push_back(make_entry(encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, geo.L), 0.0f, hy.c, hy));
+                o.a().entries.push_back(make_entry(encode_slots(nrows + 2 * g, nrows + 2 * g + 1, false, geo.L), 0.0f, hy.c, hy));
         o.n_steps = stepcur + 2;
         o.crit = crit;
         o.n_rows = (uint32_t)nrows;
@@ -893,7 +926,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     // MFSGD_HOST_CHUNKS=1: round 2's mixed mode (the host packs and chunks what the device declines; A/B measurements).
     const bool dev_chunks = have_info && ext && want_dev_chunks;
     // Phase 1: every cell as a single chunk, unless it cannot possibly fit.
-    std::vector<CellOut> co((size_t)ncell);
+    std::vector<CellOut> co;
+    reserve_huge(co, (size_t)ncell);
+    co.resize((size_t)ncell);
     std::vector<uint8_t> oversize((size_t)ncell, 0);
     {
         std::atomic<int64_t> next_cell{0};
@@ -1037,7 +1072,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
 
     // Phase 2: cells over the limits are cut in two (by users or by items, whichever there are more
     // of; halves balanced by rating count) until every piece fits.
-    std::vector<std::vector<CellOut>> extra((size_t)ncell);
+    std::vector<std::vector<CellOut>> extra;
+    reserve_huge(extra, (size_t)ncell);
+    extra.resize((size_t)ncell);
     std::vector<int64_t> todo;
     for (int64_t c = 0; c < ncell; ++c) {
         const CellOut& o = co[(size_t)c];
@@ -1185,7 +1222,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 if (ci.status == 0 && sched_bytes_for(geo, W, p.nu + p.ni, (int64_t)ci.n_steps) <= lim_s) {
                     Leaf lf;
                     lf.path = p.path;
-                    lf.o.subs.assign(psubs.begin() + (long)(y * (size_t)WW), psubs.begin() + (long)((y + 1) * (size_t)WW));
+                    lf.o.a().subs.assign(psubs.begin() + (long)(y * (size_t)WW), psubs.begin() + (long)((y + 1) * (size_t)WW));
                     lf.o.nu = ci.nu;
                     lf.o.ni = ci.ni;
                     lf.o.n_steps = ci.n_steps;
@@ -1194,8 +1231,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     lf.o.n_rows = ci.nu + ci.ni;
                     lf.o.n_order = (int64_t)p.idx.size();
                     lf.o.dev_part = true;
-                    lf.o.part_idx = std::move(p.idx);
-                    lf.o.part_sb = std::move(p.sb);
+                    lf.o.a().part_idx = std::move(p.idx);
+                    lf.o.a().part_sb = std::move(p.sb);
                     leaves[(size_t)p.cell].push_back(std::move(lf));
                     is_leaf[cand[y]] = 1;
                 }
@@ -1359,36 +1396,35 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         err = "build_schedule: too many chunks";
         return -1;
     }
+    reserve_huge(out.cells, (size_t)n_descs);
     out.cells.resize((size_t)n_descs);
-    out.subs.assign((size_t)(n_descs * WW) + 2, SubDesc{0, 0});  // +16 B: the staging DMA reads whole 16-byte units
+    reserve_huge(out.subs, (size_t)(n_descs * WW) + 2);
+    out.subs.resize((size_t)(n_descs * WW) + 2);  // +16 B: the staging DMA reads whole 16-byte units
+    out.subs[(size_t)(n_descs * WW)] = out.subs[(size_t)(n_descs * WW) + 1] = SubDesc{0, 0};
     std::vector<const CellOut*> by_desc((size_t)n_descs, nullptr);
     int64_t tot_rows = 0, tot_steps = 0;
     int64_t sched_cap = 0, rows_cap = 0;
+    int64_t n_dev_cells = 0, n_dev_parts = 0;
+    // per cell, compact (the loops over rounds below walk the cells with a stride of B + 1: these stay in cache,
+    // the CellOut records do not): ratings and critical steps of all its chunks; the cells that are more than one
+    // device-packed chunk, whose pieces have to be walked one by one
+    std::vector<int64_t> cell_nnz((size_t)ncell), cell_crit((size_t)ncell);
+    std::vector<int64_t> walk_cells;
     {
+        // pass 1, sequential and light: descriptor numbers, the chain of a cell's chunks, running offsets
         int64_t next_desc = ncell;
         auto place = [&](int64_t d, const CellOut& o, uint32_t next) -> bool {
             if (tot_rows > 0xFFFFFFFFll - (int64_t)o.n_rows || tot_steps > 0xFFFFFFFFll - o.n_steps) return false;
-            CellDesc cdsc{};
+            CellDesc& cdsc = out.cells[(size_t)d];
+            cdsc = CellDesc{};
             cdsc.row_off = (uint32_t)tot_rows;
             cdsc.ent_off = (uint32_t)tot_steps;
-            cdsc.n_steps = o.n_steps | (o.has_run ? kCellCritical : 0u);
-            cdsc.nu = (uint16_t)o.nu;
-            cdsc.ni = (uint16_t)o.ni;
             cdsc.next = next;
-            out.cells[(size_t)d] = cdsc;
             by_desc[(size_t)d] = &o;
-            o.desc = d;
-            if (o.dev && o.subs.empty() && d < ncell)
-                std::memcpy(&out.subs[(size_t)(d * WW)], &dsubs[(size_t)(d * WW)], sizeof(SubDesc) * (size_t)WW);
-            else
-                for (int x = 0; x < WW; ++x)
-                    out.subs[(size_t)(d * WW + x)] = o.subs.empty() ? SubDesc{0, 0} : o.subs[(size_t)x];
             tot_rows += (int64_t)o.n_rows;
             tot_steps += o.n_steps;
-            if (o.n_steps != 0) {
-                sched_cap = std::max(sched_cap, sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps));
-                rows_cap = std::max(rows_cap, rows_bytes_for(geo, (int)(o.nu + o.ni)));
-            }
+            n_dev_cells += o.dev ? 1 : 0;
+            n_dev_parts += o.dev_part ? 1 : 0;
             return true;
         };
         for (int64_t c = 0; c < ncell; ++c) {
@@ -1408,10 +1444,48 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 return -1;
             }
             if (!ex.empty()) out.split_cells++;
+            if (!ex.empty() || !co[(size_t)c].dev) walk_cells.push_back(c);
+            cell_nnz[(size_t)c] = nnz_c;
+            cell_crit[(size_t)c] = crit_c;
             out.max_cell_nnz = std::max(out.max_cell_nnz, nnz_c);
             out.max_cell_rows = std::max(out.max_cell_rows, rows_c);
             out.max_cell_steps = std::max(out.max_cell_steps, crit_c);
         }
+        // pass 2, parallel over the descriptors: the rest of each descriptor, its sub-cell table, the LDS capacities
+        std::atomic<int64_t> nx{0};
+        std::mutex mx;
+        auto fill = [&]() {
+            int64_t my_sched = 0, my_rows = 0;
+            for (;;) {
+                const int64_t d0 = nx.fetch_add(4096);
+                if (d0 >= n_descs) break;
+                for (int64_t d = d0; d < std::min(n_descs, d0 + 4096); ++d) {
+                    const CellOut& o = *by_desc[(size_t)d];
+                    CellDesc& cdsc = out.cells[(size_t)d];
+                    cdsc.n_steps = o.n_steps | (o.has_run ? kCellCritical : 0u);
+                    cdsc.nu = (uint16_t)o.nu;
+                    cdsc.ni = (uint16_t)o.ni;
+                    o.desc = d;
+                    if (o.dev && o.a().subs.empty() && d < ncell)
+                        std::memcpy(&out.subs[(size_t)(d * WW)], &dsubs[(size_t)(d * WW)], sizeof(SubDesc) * (size_t)WW);
+                    else
+                        for (int x = 0; x < WW; ++x)
+                            out.subs[(size_t)(d * WW + x)] = o.a().subs.empty() ? SubDesc{0, 0} : o.a().subs[(size_t)x];
+                    if (o.n_steps != 0) {
+                        my_sched = std::max(my_sched, sched_bytes_for(geo, W, (int)(o.nu + o.ni), (int64_t)o.n_steps));
+                        my_rows = std::max(my_rows, rows_bytes_for(geo, (int)(o.nu + o.ni)));
+                    }
+                }
+            }
+            std::lock_guard<std::mutex> lk(mx);
+            sched_cap = std::max(sched_cap, my_sched);
+            rows_cap = std::max(rows_cap, my_rows);
+        };
+        std::vector<std::thread> th;
+        const int nt = n_descs >= 65536 ? nthreads : 1;
+        for (int t = 1; t < nt; ++t) th.emplace_back(fill);
+        fill();
+        for (auto& t : th) t.join();
     }
     mark_lone_tiles(out.cells, B, geo, tile_items);
     lap("  offsets");
@@ -1437,13 +1511,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         for (int b = 0; b < B; ++b) {
             const int64_t c = (int64_t)b * B + (b + rd) % B;
             out.cell_ptr[(size_t)((int64_t)rd * B + b)] = pos;
-            int64_t crit_c = co[(size_t)c].crit;
-            pos += co[(size_t)c].n_order;
-            for (const CellOut& o : extra[(size_t)c]) {
-                pos += o.n_order;
-                crit_c += o.crit;
-            }
-            worst = std::max(worst, crit_c);
+            pos += cell_nnz[(size_t)c];
+            worst = std::max(worst, cell_crit[(size_t)c]);
         }
         out.sum_round_steps += worst;
     }
@@ -1451,11 +1520,6 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     if (pos != n) {
         err = "build_schedule: internal error, packed " + std::to_string(pos) + " of " + std::to_string(n);
         return -1;
-    }
-    int64_t n_dev_cells = 0, n_dev_parts = 0;
-    for (int64_t x = 0; x < n_descs; ++x) {
-        n_dev_cells += by_desc[(size_t)x]->dev ? 1 : 0;
-        n_dev_parts += by_desc[(size_t)x]->dev_part ? 1 : 0;
     }
     if (n_dev_cells > 0 || n_dev_parts > 0) {
         // ---- mixed finish: the device writes its cells at their final places (EMIT pass); the chunks of the cells that
@@ -1475,30 +1539,42 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             p_ro.reserve((size_t)n_dev_parts);
             p_eo.reserve((size_t)n_dev_parts);
         }
-        for (int64_t x = 0; x < n_descs; ++x) {
+        // (device cells are first chunks, x < ncell, and most of all descriptors: they are skipped through the compact
+        // list of the cells that are anything else)
+        for (int64_t x = 0; x < ncell; ++x) {
+            row_off[(size_t)x] = out.cells[(size_t)x].row_off;
+            ent_off[(size_t)x] = out.cells[(size_t)x].ent_off;
+        }
+        std::vector<int64_t> other_descs;
+        for (const int64_t c : walk_cells) {
+            if (!co[(size_t)c].dev) {
+                row_off[(size_t)c] = 0xFFFFFFFFu;
+                ent_off[(size_t)c] = 0u;
+                other_descs.push_back(c);
+            }
+            for (const CellOut& o : extra[(size_t)c]) other_descs.push_back(o.desc);
+        }
+        std::sort(other_descs.begin(), other_descs.end());
+        for (const int64_t x : other_descs) {
             const CellOut& o = *by_desc[(size_t)x];
             const CellDesc& d = out.cells[(size_t)x];
-            if (o.dev) {
-                row_off[(size_t)x] = d.row_off;  // (device cells are first chunks: x < ncell)
-                ent_off[(size_t)x] = d.ent_off;
-                continue;
-            }
+            if (o.dev) continue;  // (a cell's later chunks are never device CELLS; kept for symmetry)
             if (o.dev_part) {
                 part_of_desc[(size_t)x] = (int64_t)p_ro.size();
                 p_ro.push_back(d.row_off);
                 p_eo.push_back(d.ent_off);
                 p_desc.push_back(x);
                 p_at.push_back(p_total);  // where its ratings start in the concatenated list (filled in parallel below)
-                p_total += (int64_t)o.part_idx.size();
+                p_total += (int64_t)o.a().part_idx.size();
                 continue;
             }
-            if (!o.rows.empty()) {
-                mp.seg_rows.push_back({(uint64_t)d.row_off, (uint64_t)mp.rows.size(), (uint64_t)o.rows.size()});
-                mp.rows.insert(mp.rows.end(), o.rows.begin(), o.rows.end());
+            if (!o.a().rows.empty()) {
+                mp.seg_rows.push_back({(uint64_t)d.row_off, (uint64_t)mp.rows.size(), (uint64_t)o.a().rows.size()});
+                mp.rows.insert(mp.rows.end(), o.a().rows.begin(), o.a().rows.end());
             }
-            if (!o.entries.empty()) {
-                mp.seg_entries.push_back({(uint64_t)d.ent_off * G, (uint64_t)mp.entries.size(), (uint64_t)o.entries.size()});
-                mp.entries.insert(mp.entries.end(), o.entries.begin(), o.entries.end());
+            if (!o.a().entries.empty()) {
+                mp.seg_entries.push_back({(uint64_t)d.ent_off * G, (uint64_t)mp.entries.size(), (uint64_t)o.a().entries.size()});
+                mp.entries.insert(mp.entries.end(), o.a().entries.begin(), o.a().entries.end());
             }
         }
         if (n_dev_parts > 0) {
@@ -1513,11 +1589,11 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     for (size_t y = y0; y < std::min(p_desc.size(), y0 + 64); ++y) {
                         const CellOut& o = *by_desc[(size_t)p_desc[y]];
                         const int64_t base = p_at[y];
-                        std::memcpy(&p_idx[(size_t)base], o.part_idx.data(), o.part_idx.size() * sizeof(uint32_t));
+                        std::memcpy(&p_idx[(size_t)base], o.a().part_idx.data(), o.a().part_idx.size() * sizeof(uint32_t));
                         size_t at = 0;
                         for (int sbi = 0; sbi < WW; ++sbi) {
                             p_cptr[y * (size_t)WW + (size_t)sbi] = base + (int64_t)at;
-                            while (at < o.part_sb.size() && o.part_sb[at] == (uint16_t)sbi) ++at;
+                            while (at < o.a().part_sb.size() && o.a().part_sb[at] == (uint16_t)sbi) ++at;
                         }
                     }
                 }
@@ -1531,15 +1607,16 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         p_oo.assign(p_ro.size(), 0);
         for (int64_t x = 0; x < ncell; ++x) {
             const int64_t rd = x / B, b = x % B;
-            const int64_t c = b * B + (b + rd) % B;
-            int64_t at = out.cell_ptr[(size_t)x];
-            ord_off[(size_t)c] = at;
+            ord_off[(size_t)(b * B + (b + rd) % B)] = out.cell_ptr[(size_t)x];
+        }
+        for (const int64_t c : walk_cells) {
+            int64_t at = ord_off[(size_t)c];
             auto piece = [&](const CellOut& o) {
                 if (o.dev_part) {
                     p_oo[(size_t)part_of_desc[(size_t)o.desc]] = at;
-                } else if (!o.dev && !o.order.empty()) {
-                    mp.seg_order.push_back({(uint64_t)at, (uint64_t)mp.order.size(), (uint64_t)o.order.size()});
-                    mp.order.insert(mp.order.end(), o.order.begin(), o.order.end());
+                } else if (!o.dev && !o.a().order.empty()) {
+                    mp.seg_order.push_back({(uint64_t)at, (uint64_t)mp.order.size(), (uint64_t)o.a().order.size()});
+                    mp.order.insert(mp.order.end(), o.a().order.begin(), o.a().order.end());
                 }
                 at += o.n_order;
             };
@@ -1594,11 +1671,11 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 for (int64_t x = c; x < std::min<int64_t>(c + 64, n_descs); ++x) {
                     const CellOut& o = *by_desc[(size_t)x];
                     const CellDesc& d = out.cells[(size_t)x];
-                    if (!o.rows.empty())
-                        std::memcpy(&out.rows[d.row_off], o.rows.data(), o.rows.size() * sizeof(uint32_t));
-                    if (!o.entries.empty())
-                        std::memcpy(&out.entries[(size_t)d.ent_off * G], o.entries.data(),
-                                    o.entries.size() * sizeof(Entry));
+                    if (!o.a().rows.empty())
+                        std::memcpy(&out.rows[d.row_off], o.a().rows.data(), o.a().rows.size() * sizeof(uint32_t));
+                    if (!o.a().entries.empty())
+                        std::memcpy(&out.entries[(size_t)d.ent_off * G], o.a().entries.data(),
+                                    o.a().entries.size() * sizeof(Entry));
                 }
             }
         };
@@ -1621,8 +1698,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     const int64_t c = b * B + (b + rd) % B;
                     int64_t at = out.cell_ptr[(size_t)x];
                     auto append = [&](const CellOut& o) {
-                        if (!o.order.empty())
-                            std::memcpy(&out.order[(size_t)at], o.order.data(), o.order.size() * sizeof(int64_t));
+                        if (!o.a().order.empty())
+                            std::memcpy(&out.order[(size_t)at], o.a().order.data(), o.a().order.size() * sizeof(int64_t));
                         at += o.n_order;
                     };
                     append(co[(size_t)c]);

@@ -445,6 +445,21 @@ def test_device_packer_mixed_mode_chunked_cells(mf, oracle):
     assert info["device_ingest"] == 2
 
 
+def test_device_packer_one_pass_and_two_pass_write_the_same_bytes(mf, monkeypatch):
+    """[r3] The packing kernel writes what it packs during its COUNT pass (scratch arrays at worst-case offsets, moved by
+    compact_kernel); MFSGD_PACK_TWICE=1 keeps the COUNT + EMIT form.  Both against the host packer's bytes, with and
+    without cells that are cut (whose scratch is dropped and whose chunks are packed from their lists)."""
+    cases = (("cfg2_ml20m", 0.02), ("cfg3_netflix", 0.02), ("cfg4_powerlaw", 0.0003), ("cfg1_ml100k", 1.0))
+    for twice in (False, True):
+        if twice:
+            monkeypatch.setenv("MFSGD_PACK_TWICE", "1")
+        else:
+            monkeypatch.delenv("MFSGD_PACK_TWICE", raising=False)
+        for name, scale in cases:
+            w = mf.synth.workload(name, scale)
+            _same_schedule(mf, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"])
+
+
 def test_device_packer_partitioned_handles(mf):
     """n_parts > 1: every partition's schedule through the device packer (the caller-visible rating
     indices go through the `orig` map)."""
