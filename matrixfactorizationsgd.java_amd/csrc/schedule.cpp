@@ -155,10 +155,6 @@ struct CellArrays {
     std::vector<Entry> entries;
     std::vector<SubDesc> subs;
     std::vector<int64_t> order;
-    // [r3] a CHUNK the device packs (a part of a cell that was cut): its ratings as indices into the caller's arrays, in
-    // the cell's bucket order, with the sub-cell of each -- the packing kernel takes the list as a cell of its own
-    std::vector<uint32_t> part_idx;
-    std::vector<uint16_t> part_sb;
 };
 
 struct CellOut {
@@ -178,7 +174,12 @@ struct CellOut {
     uint32_t n_rows = 0;
     int64_t n_order = 0;
     bool dev = false;       // packed by the device packer: rows / entries / order are not here
-    bool dev_part = false;  // a chunk the device packs from part_idx / part_sb
+    // [r3] a CHUNK the device packs (a part of a cell that was cut): its ratings are the range [part_lo, part_lo +
+    // n_order) of build_schedule's `part_ratings` (indices into the caller's arrays, in the cell's bucket order, the
+    // sub-cell of each beside it) -- the packing kernel takes the range as a cell of its own; its sub-cell table is
+    // entry part_tab of `part_subs`
+    bool dev_part = false;
+    int64_t part_lo = -1, part_tab = -1;
     mutable int64_t desc = -1;  // its chunk descriptor, once placed
 };
 
@@ -1083,27 +1084,32 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                                 rows_bytes_for(geo, (int)(o.nu + o.ni)) > lim_r)))
             todo.push_back(c);
     }
+    // [r3] The ratings of the cells that are cut (indices into the caller's arrays), cell after cell in bucket order, and
+    // the sub-cell of each.  The cut tree partitions a cell's range IN PLACE (stably), so every part -- and in the end
+    // every chunk -- is a range of these two arrays, a cell's chunks lie in chain order one behind the other, and the
+    // arrays as they stand are the rating lists the device's EMIT pass takes: no per-part vectors, nothing concatenated.
+    std::vector<uint32_t> part_ratings;
+    std::vector<uint16_t> part_sbs;
+    std::vector<SubDesc> part_subs;  // W*W per chunk, in the order the chunks were accepted
     if (dev_chunks && !todo.empty()) {
         // The same cut tree as the host recursion below, grown level by level: a part whose rows fit is a candidate
         // and the device's COUNT pass says how many steps it packs into; a candidate within the limits is a leaf (a
         // chunk), everything else is cut at the same pivot the recursion would take.  A leaf's place among its cell's
-        // chunks is its path in the tree (left before right).
+        // chunks is its path in the tree (left before right) -- which is its place in the arrays.
         struct Part {
-            int64_t cell;
-            uint64_t path;  // bit (63 - d) = went right at depth d
+            int64_t lo, hi;  // its range of part_ratings
             int depth;
-            std::vector<uint32_t> idx;
-            std::vector<uint16_t> sb;
             int nu = 0, ni = 0;
             bool candidate = false;
             bool by_user = false;   // the cut this part gets if it is not a leaf ...
             uint32_t pivot = 0;     // ... ids >= pivot go right
         };
         struct Leaf {
-            uint64_t path;
-            CellOut o;
+            int64_t lo, hi;
+            PackCellInfo ci;
+            int64_t tab;  // its sub-cell table in part_subs
         };
-        std::vector<std::vector<Leaf>> leaves((size_t)todo.size());
+        std::vector<Leaf> leaves;
         std::vector<Part> level;
         level.reserve(todo.size());
         // the bucket order of the cells to be cut, and of those only
@@ -1114,80 +1120,105 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             r_len[x] = bptr[(size_t)((c + 1) * WW)] - r_lo[x];
             r_at[x + 1] = r_at[x] + r_len[x];
         }
-        std::vector<uint32_t> cut_sorted((size_t)r_at[todo.size()]);
-        if (ext->fetch_sorted_ranges(prm.ingest->ctx, (int64_t)todo.size(), r_lo.data(), r_len.data(), cut_sorted.data()) != 0) {
+        const int64_t n_cut = r_at[todo.size()];
+        reserve_huge(part_ratings, (size_t)n_cut);
+        part_ratings.resize((size_t)n_cut);
+        if (ext->fetch_sorted_ranges(prm.ingest->ctx, (int64_t)todo.size(), r_lo.data(), r_len.data(), part_ratings.data()) != 0) {
             err = "build_schedule: could not fetch the bucket order of the cells to be cut from the device";
             return -1;
         }
         lap("  bucket order of the cut cells to the host");
-        for (size_t x = 0; x < todo.size(); ++x) {
-            const int64_t c = todo[x];
-            Part p;
-            p.cell = (int64_t)x;
-            p.path = 0;
-            p.depth = 0;
-            const int64_t lo = r_lo[x], hi = lo + r_len[x];
-            p.idx.assign(cut_sorted.begin() + (long)r_at[x], cut_sorted.begin() + (long)r_at[x + 1]);
-            p.sb.resize((size_t)(hi - lo));
-            int sbi = 0;
-            for (int64_t y = lo; y < hi; ++y) {
-                while (bptr[(size_t)(c * WW + sbi + 1)] <= y) ++sbi;
-                p.sb[(size_t)(y - lo)] = (uint16_t)sbi;
+        reserve_huge(part_sbs, (size_t)n_cut);
+        part_sbs.resize((size_t)n_cut);
+        auto on_all_threads = [&](size_t n_items, size_t grain, const std::function<void(size_t, size_t)>& body) {
+            std::atomic<size_t> nx{0};
+            auto work = [&]() {
+                for (;;) {
+                    const size_t x0 = nx.fetch_add(grain);
+                    if (x0 >= n_items) break;
+                    body(x0, std::min(n_items, x0 + grain));
+                }
+            };
+            std::vector<std::thread> th;
+            const size_t want = (n_items + grain - 1) / grain;
+            for (int t = 1; t < (int)std::min<size_t>((size_t)nthreads, want); ++t) th.emplace_back(work);
+            work();
+            for (auto& t : th) t.join();
+        };
+        on_all_threads(todo.size(), 16, [&](size_t x0, size_t x1) {
+            for (size_t x = x0; x < x1; ++x) {
+                const int64_t c = todo[x];
+                const int64_t lo = r_lo[x], hi = lo + r_len[x];
+                int sbi = 0;
+                for (int64_t y = lo; y < hi; ++y) {
+                    while (bptr[(size_t)(c * WW + sbi + 1)] <= y) ++sbi;
+                    part_sbs[(size_t)(r_at[x] + (y - lo))] = (uint16_t)sbi;
+                }
             }
-            level.push_back(std::move(p));
+        });
+        for (size_t x = 0; x < todo.size(); ++x) {
+            Part p;
+            p.lo = r_at[x];
+            p.hi = r_at[x + 1];
+            p.depth = 0;
+            level.push_back(p);
         }
-        std::vector<uint32_t>().swap(cut_sorted);
         bool root = true;
+        double t_rows = 0, t_lists = 0, t_count = 0, t_cut = 0;  // MFSGD_SCHED_TRACE: where the levels' time goes
+        int n_levels = 0;
+        auto since = [](std::chrono::steady_clock::time_point& t) {
+            const auto now = std::chrono::steady_clock::now();
+            const double d = std::chrono::duration<double>(now - t).count();
+            t = now;
+            return d;
+        };
+        auto t_lvl = std::chrono::steady_clock::now();
         while (!level.empty() && !failed.load()) {
+            ++n_levels;
+            (void)since(t_lvl);
             // 1. distinct rows of every part; whole cells (the roots) are known not to fit: they are cut unseen
-            {
-                std::atomic<size_t> nx{0};
-                auto work = [&]() {
-                    std::vector<uint32_t> us, is;
-                    for (;;) {
-                        const size_t x = nx.fetch_add(1);
-                        if (x >= level.size()) break;
-                        Part& p = level[x];
-                        us.resize(p.idx.size());
-                        is.resize(p.idx.size());
-                        for (size_t y = 0; y < p.idx.size(); ++y) {
-                            us[y] = (uint32_t)u[p.idx[y]];
-                            is[y] = (uint32_t)i[p.idx[y]];
-                        }
-                        std::sort(us.begin(), us.end());
-                        std::sort(is.begin(), is.end());
-                        auto distinct = [](const std::vector<uint32_t>& v) {
-                            int n = 0;
-                            for (size_t y = 0; y < v.size(); ++y) n += y == 0 || v[y] != v[y - 1];
-                            return n;
-                        };
-                        p.nu = distinct(us);
-                        p.ni = distinct(is);
-                        const int nrows = p.nu + p.ni;
-                        p.candidate = !root && addressable(nrows) && rows_bytes_for(geo, nrows) <= lim_r;
-                        // the pivot of the cut, should there be one: the first distinct id (position >= 1) at which the
-                        // ratings of the ids before it reach half of the part (the host recursion's rule)
-                        p.by_user = (p.nu >= p.ni && p.nu > 1) || p.ni <= 1;
-                        const std::vector<uint32_t>& v = p.by_user ? us : is;
-                        const int nid = p.by_user ? p.nu : p.ni;
-                        const int64_t half = (int64_t)v.size() / 2;
-                        int seen = 0;  // distinct ids passed
-                        p.pivot = v.empty() ? 0u : v[0];
-                        for (size_t y = 0; y < v.size(); ++y) {
-                            if (y > 0 && v[y] != v[y - 1]) {
-                                // y ratings belong to the `seen + 1` ids before v[y]
-                                ++seen;
-                                p.pivot = v[y];
-                                if ((int64_t)y >= half || seen >= nid - 1) break;
-                            }
+            on_all_threads(level.size(), 1, [&](size_t x0, size_t x1) {
+                thread_local std::vector<uint32_t> us, is;
+                for (size_t x = x0; x < x1; ++x) {
+                    Part& p = level[x];
+                    const size_t m = (size_t)(p.hi - p.lo);
+                    us.resize(m);
+                    is.resize(m);
+                    for (size_t y = 0; y < m; ++y) {
+                        const uint32_t j = part_ratings[(size_t)p.lo + y];
+                        us[y] = (uint32_t)u[j];
+                        is[y] = (uint32_t)i[j];
+                    }
+                    std::sort(us.begin(), us.end());
+                    std::sort(is.begin(), is.end());
+                    auto distinct = [](const std::vector<uint32_t>& v) {
+                        int n = 0;
+                        for (size_t y = 0; y < v.size(); ++y) n += y == 0 || v[y] != v[y - 1];
+                        return n;
+                    };
+                    p.nu = distinct(us);
+                    p.ni = distinct(is);
+                    const int nrows = p.nu + p.ni;
+                    p.candidate = !root && addressable(nrows) && rows_bytes_for(geo, nrows) <= lim_r;
+                    // the pivot of the cut, should there be one: the first distinct id (position >= 1) at which the
+                    // ratings of the ids before it reach half of the part (the host recursion's rule)
+                    p.by_user = (p.nu >= p.ni && p.nu > 1) || p.ni <= 1;
+                    const std::vector<uint32_t>& v = p.by_user ? us : is;
+                    const int nid = p.by_user ? p.nu : p.ni;
+                    const int64_t half = (int64_t)v.size() / 2;
+                    int seen = 0;  // distinct ids passed
+                    p.pivot = v.empty() ? 0u : v[0];
+                    for (size_t y = 0; y < v.size(); ++y) {
+                        if (y > 0 && v[y] != v[y - 1]) {
+                            // y ratings belong to the `seen + 1` ids before v[y]
+                            ++seen;
+                            p.pivot = v[y];
+                            if ((int64_t)y >= half || seen >= nid - 1) break;
                         }
                     }
-                };
-                std::vector<std::thread> th;
-                for (int t = 1; t < (int)std::min<size_t>((size_t)nthreads, level.size()); ++t) th.emplace_back(work);
-                work();
-                for (auto& t : th) t.join();
-            }
+                }
+            });
+            t_rows += since(t_lvl);
             // 2. the candidates' sizes, from the device
             std::vector<size_t> cand;
             for (size_t x = 0; x < level.size(); ++x)
@@ -1195,61 +1226,62 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             std::vector<PackCellInfo> pinfo(cand.size());
             std::vector<SubDesc> psubs(cand.size() * (size_t)WW);
             if (!cand.empty()) {
+                std::vector<int64_t> c_at(cand.size() + 1, 0);
+                for (size_t y = 0; y < cand.size(); ++y) c_at[y + 1] = c_at[y] + (level[cand[y]].hi - level[cand[y]].lo);
                 std::vector<uint32_t> lst;
+                reserve_huge(lst, (size_t)c_at[cand.size()]);
+                lst.resize((size_t)c_at[cand.size()]);
                 std::vector<int64_t> cptr(cand.size() * (size_t)WW + 1, 0);
-                for (size_t y = 0; y < cand.size(); ++y) {
-                    const Part& p = level[cand[y]];
-                    size_t at = 0;
-                    for (int sbi = 0; sbi < WW; ++sbi) {
-                        cptr[y * (size_t)WW + (size_t)sbi] = (int64_t)(lst.size() + at);
-                        while (at < p.sb.size() && p.sb[at] == (uint16_t)sbi) ++at;
+                on_all_threads(cand.size(), 64, [&](size_t y0, size_t y1) {
+                    for (size_t y = y0; y < y1; ++y) {
+                        const Part& p = level[cand[y]];
+                        const size_t m = (size_t)(p.hi - p.lo);
+                        std::memcpy(&lst[(size_t)c_at[y]], &part_ratings[(size_t)p.lo], m * sizeof(uint32_t));
+                        const uint16_t* sb = &part_sbs[(size_t)p.lo];
+                        size_t at = 0;
+                        for (int sbi = 0; sbi < WW; ++sbi) {
+                            cptr[y * (size_t)WW + (size_t)sbi] = c_at[y] + (int64_t)at;
+                            while (at < m && sb[at] == (uint16_t)sbi) ++at;
+                        }
                     }
-                    lst.insert(lst.end(), p.idx.begin(), p.idx.end());
-                }
-                cptr[cand.size() * (size_t)WW] = (int64_t)lst.size();
+                });
+                cptr[cand.size() * (size_t)WW] = c_at[cand.size()];
+                t_lists += since(t_lvl);
                 if (ext->pack_count_parts(prm.ingest->ctx, (int64_t)cand.size(), lst.data(), (int64_t)lst.size(), cptr.data(),
                                           pinfo.data(), psubs.data()) != 0) {
                     err = "build_schedule: the device packer's COUNT pass over the chunks failed";
                     return -1;
                 }
             }
+            t_count += since(t_lvl);
             // 3. leaves and cuts
             std::vector<Part> next;
             std::vector<uint8_t> is_leaf(level.size(), 0);
             for (size_t y = 0; y < cand.size(); ++y) {
-                Part& p = level[cand[y]];
+                const Part& p = level[cand[y]];
                 const PackCellInfo& ci = pinfo[y];
                 if (ci.status == 0 && sched_bytes_for(geo, W, p.nu + p.ni, (int64_t)ci.n_steps) <= lim_s) {
                     Leaf lf;
-                    lf.path = p.path;
-                    lf.o.a().subs.assign(psubs.begin() + (long)(y * (size_t)WW), psubs.begin() + (long)((y + 1) * (size_t)WW));
-                    lf.o.nu = ci.nu;
-                    lf.o.ni = ci.ni;
-                    lf.o.n_steps = ci.n_steps;
-                    lf.o.crit = ci.crit;
-                    lf.o.has_run = ci.has_run != 0;
-                    lf.o.n_rows = ci.nu + ci.ni;
-                    lf.o.n_order = (int64_t)p.idx.size();
-                    lf.o.dev_part = true;
-                    lf.o.a().part_idx = std::move(p.idx);
-                    lf.o.a().part_sb = std::move(p.sb);
-                    leaves[(size_t)p.cell].push_back(std::move(lf));
+                    lf.lo = p.lo;
+                    lf.hi = p.hi;
+                    lf.ci = ci;
+                    lf.tab = (int64_t)(part_subs.size() / (size_t)WW);
+                    part_subs.insert(part_subs.end(), psubs.begin() + (long)(y * (size_t)WW), psubs.begin() + (long)((y + 1) * (size_t)WW));
+                    leaves.push_back(lf);
                     is_leaf[cand[y]] = 1;
                 }
             }
             {
                 std::mutex mu;
-                std::atomic<size_t> nx{0};
-                auto work = [&]() {
-                    std::vector<uint32_t> ids;
-                    std::vector<int64_t> cnt;
+                on_all_threads(level.size(), 4, [&](size_t x0, size_t x1) {
+                    thread_local std::vector<uint32_t> hold_idx;
+                    thread_local std::vector<uint16_t> hold_sb;
                     std::vector<Part> mine;
-                    for (;;) {
-                        const size_t x = nx.fetch_add(1);
-                        if (x >= level.size()) break;
+                    for (size_t x = x0; x < x1 && !failed.load(); ++x) {
                         if (is_leaf[x]) continue;
-                        Part& p = level[x];
-                        if (p.idx.size() <= 1) {
+                        const Part& p = level[x];
+                        const int64_t m = p.hi - p.lo;
+                        if (m <= 1) {
                             if (!failed.exchange(1)) fail_msg = "lds: a single rating does not fit the chunk limits";
                             break;
                         }
@@ -1257,56 +1289,84 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                             if (!failed.exchange(1)) fail_msg = "build_schedule: a cell was cut more than 62 times";
                             break;
                         }
-                        Part l, r2;
-                        l.cell = r2.cell = p.cell;
-                        l.depth = r2.depth = p.depth + 1;
-                        l.path = p.path;
-                        r2.path = p.path | (1ull << (63 - p.depth));
+                        int64_t nl;
                         if (p.nu <= 1 && p.ni <= 1) {
-                            // the same (user, item) pair many times over: any cut of the sequence will do
-                            const size_t half = p.idx.size() / 2;
-                            l.idx.assign(p.idx.begin(), p.idx.begin() + (long)half);
-                            l.sb.assign(p.sb.begin(), p.sb.begin() + (long)half);
-                            r2.idx.assign(p.idx.begin() + (long)half, p.idx.end());
-                            r2.sb.assign(p.sb.begin() + (long)half, p.sb.end());
+                            nl = m / 2;  // the same (user, item) pair many times over: any cut of the sequence will do
                         } else {
+                            // stable partition of the range in place: the lefts close up (a write never passes the
+                            // read position), the rights wait in a buffer and follow
                             const int32_t* key_of = p.by_user ? u : i;
                             const uint32_t pivot = p.pivot;
-                            l.idx.reserve(p.idx.size() / 2 + 8);
-                            r2.idx.reserve(p.idx.size() / 2 + 8);
-                            for (size_t y = 0; y < p.idx.size(); ++y) {
-                                Part& dst = (uint32_t)key_of[p.idx[y]] < pivot ? l : r2;
-                                dst.idx.push_back(p.idx[y]);
-                                dst.sb.push_back(p.sb[y]);
+                            uint32_t* idx = &part_ratings[(size_t)p.lo];
+                            uint16_t* sb = &part_sbs[(size_t)p.lo];
+                            hold_idx.clear();
+                            hold_sb.clear();
+                            nl = 0;
+                            for (int64_t y = 0; y < m; ++y) {
+                                if ((uint32_t)key_of[idx[y]] < pivot) {
+                                    idx[nl] = idx[y];
+                                    sb[nl] = sb[y];
+                                    ++nl;
+                                } else {
+                                    hold_idx.push_back(idx[y]);
+                                    hold_sb.push_back(sb[y]);
+                                }
                             }
+                            std::memcpy(idx + nl, hold_idx.data(), hold_idx.size() * sizeof(uint32_t));
+                            std::memcpy(sb + nl, hold_sb.data(), hold_sb.size() * sizeof(uint16_t));
                         }
-                        std::vector<uint32_t>().swap(p.idx);
-                        std::vector<uint16_t>().swap(p.sb);
-                        mine.push_back(std::move(l));
-                        mine.push_back(std::move(r2));
+                        Part l, r2;
+                        l.depth = r2.depth = p.depth + 1;
+                        l.lo = p.lo;
+                        l.hi = r2.lo = p.lo + nl;
+                        r2.hi = p.hi;
+                        mine.push_back(l);
+                        mine.push_back(r2);
                     }
                     std::lock_guard<std::mutex> lk(mu);
-                    for (Part& q : mine) next.push_back(std::move(q));
-                };
-                std::vector<std::thread> th;
-                for (int t = 1; t < (int)std::min<size_t>((size_t)nthreads, level.size()); ++t) th.emplace_back(work);
-                work();
-                for (auto& t : th) t.join();
+                    next.insert(next.end(), mine.begin(), mine.end());
+                });
             }
             level = std::move(next);
             root = false;
+            t_cut += since(t_lvl);
         }
+        if (trace)
+            std::fprintf(stderr, "[schedule]     %d levels: rows + pivots %.3f s, candidate lists %.3f s, device COUNT %.3f s, leaves + cuts %.3f s\n",
+                         n_levels, t_rows, t_lists, t_count, t_cut);
         if (!failed.load()) {
-            for (size_t x = 0; x < todo.size(); ++x) {
-                std::vector<Leaf>& lv = leaves[x];
-                std::sort(lv.begin(), lv.end(), [](const Leaf& a, const Leaf& b) { return a.path < b.path; });
-                if (lv.empty()) {
-                    if (!failed.exchange(1)) fail_msg = "build_schedule: internal error, a cut cell has no chunk";
+            // a cell's chunks in chain order = its leaves by position
+            std::sort(leaves.begin(), leaves.end(), [](const Leaf& a, const Leaf& b) { return a.lo < b.lo; });
+            size_t at = 0;
+            for (size_t x = 0; x < todo.size() && !failed.load(); ++x) {
+                size_t end = at;
+                while (end < leaves.size() && leaves[end].lo < r_at[x + 1]) ++end;
+                // (the leaves of a cell tile its range: first at its start, each at the end of the one before, last at its end)
+                bool tiles = end > at && leaves[at].lo == r_at[x] && leaves[end - 1].hi == r_at[x + 1];
+                for (size_t y = at + 1; tiles && y < end; ++y) tiles = leaves[y].lo == leaves[y - 1].hi;
+                if (!tiles) {
+                    if (!failed.exchange(1)) fail_msg = "build_schedule: internal error, a cut cell's chunks do not tile its ratings";
                     break;
                 }
                 const int64_t c = todo[x];
-                co[(size_t)c] = std::move(lv[0].o);
-                for (size_t y = 1; y < lv.size(); ++y) extra[(size_t)c].push_back(std::move(lv[y].o));
+                auto chunk_of = [&](const Leaf& lf) {
+                    CellOut o;
+                    o.nu = lf.ci.nu;
+                    o.ni = lf.ci.ni;
+                    o.n_steps = lf.ci.n_steps;
+                    o.crit = lf.ci.crit;
+                    o.has_run = lf.ci.has_run != 0;
+                    o.n_rows = lf.ci.nu + lf.ci.ni;
+                    o.n_order = lf.hi - lf.lo;
+                    o.dev_part = true;
+                    o.part_lo = lf.lo;
+                    o.part_tab = lf.tab;
+                    return o;
+                };
+                co[(size_t)c] = chunk_of(leaves[at]);
+                extra[(size_t)c].reserve(end - at - 1);
+                for (size_t y = at + 1; y < end; ++y) extra[(size_t)c].push_back(chunk_of(leaves[y]));
+                at = end;
             }
         }
     } else {
@@ -1468,6 +1528,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     o.desc = d;
                     if (o.dev && o.a().subs.empty() && d < ncell)
                         std::memcpy(&out.subs[(size_t)(d * WW)], &dsubs[(size_t)(d * WW)], sizeof(SubDesc) * (size_t)WW);
+                    else if (o.dev_part)
+                        std::memcpy(&out.subs[(size_t)(d * WW)], &part_subs[(size_t)(o.part_tab * WW)], sizeof(SubDesc) * (size_t)WW);
                     else
                         for (int x = 0; x < WW; ++x)
                             out.subs[(size_t)(d * WW + x)] = o.a().subs.empty() ? SubDesc{0, 0} : o.a().subs[(size_t)x];
@@ -1528,22 +1590,17 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         MixedPieces mp;
         std::vector<uint32_t> row_off((size_t)ncell, 0xFFFFFFFFu), ent_off((size_t)ncell, 0u);
         std::vector<int64_t> ord_off((size_t)ncell, 0);
-        std::vector<uint32_t> p_idx, p_ro, p_eo;
+        std::vector<uint32_t> p_ro, p_eo;
         std::vector<int64_t> p_cptr, p_oo;
-        std::vector<int64_t> part_of_desc((size_t)n_descs, -1);
-        std::vector<int64_t> p_desc, p_at;
-        int64_t p_total = 0;
-        if (n_dev_parts > 0) {
-            p_desc.reserve((size_t)n_dev_parts);
-            p_at.reserve((size_t)n_dev_parts);
-            p_ro.reserve((size_t)n_dev_parts);
-            p_eo.reserve((size_t)n_dev_parts);
-        }
         // (device cells are first chunks, x < ncell, and most of all descriptors: they are skipped through the compact
         // list of the cells that are anything else)
         for (int64_t x = 0; x < ncell; ++x) {
             row_off[(size_t)x] = out.cells[(size_t)x].row_off;
             ent_off[(size_t)x] = out.cells[(size_t)x].ent_off;
+        }
+        for (int64_t x = 0; x < ncell; ++x) {
+            const int64_t rd = x / B, b = x % B;
+            ord_off[(size_t)(b * B + (b + rd) % B)] = out.cell_ptr[(size_t)x];
         }
         std::vector<int64_t> other_descs;
         for (const int64_t c : walk_cells) {
@@ -1558,16 +1615,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         for (const int64_t x : other_descs) {
             const CellOut& o = *by_desc[(size_t)x];
             const CellDesc& d = out.cells[(size_t)x];
-            if (o.dev) continue;  // (a cell's later chunks are never device CELLS; kept for symmetry)
-            if (o.dev_part) {
-                part_of_desc[(size_t)x] = (int64_t)p_ro.size();
-                p_ro.push_back(d.row_off);
-                p_eo.push_back(d.ent_off);
-                p_desc.push_back(x);
-                p_at.push_back(p_total);  // where its ratings start in the concatenated list (filled in parallel below)
-                p_total += (int64_t)o.a().part_idx.size();
-                continue;
-            }
+            if (o.dev || o.dev_part) continue;  // (the device's chunks: below, in the order of their rating lists)
             if (!o.a().rows.empty()) {
                 mp.seg_rows.push_back({(uint64_t)d.row_off, (uint64_t)mp.rows.size(), (uint64_t)o.a().rows.size()});
                 mp.rows.insert(mp.rows.end(), o.a().rows.begin(), o.a().rows.end());
@@ -1578,43 +1626,67 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             }
         }
         if (n_dev_parts > 0) {
-            // the chunks' rating lists one after another, and their W*W sub-cell starts: independent per chunk
-            p_idx.resize((size_t)p_total);
-            p_cptr.assign(p_ro.size() * (size_t)WW + 1, 0);
+            // The chunks the device packs, in the order of their ranges of part_ratings (cut cell after cut cell, a
+            // cell's chunks in chain order): where each goes, and its W*W sub-cell starts -- independent per chunk.
+            // A chunk's place in the canonical order is its cell's plus the ratings of the chunks before it, which is
+            // its distance from the first chunk in part_ratings.
+            std::vector<const CellOut*> parts;
+            parts.reserve((size_t)n_dev_parts);
+            std::vector<int64_t> part_cell;
+            part_cell.reserve((size_t)n_dev_parts);
+            for (const int64_t c : walk_cells) {
+                if (co[(size_t)c].dev_part) {
+                    parts.push_back(&co[(size_t)c]);
+                    part_cell.push_back(c);
+                }
+                for (const CellOut& o : extra[(size_t)c])
+                    if (o.dev_part) {
+                        parts.push_back(&o);
+                        part_cell.push_back(c);
+                    }
+            }
+            bool in_order = (int64_t)parts.size() == n_dev_parts && !parts.empty() && parts[0]->part_lo == 0;
+            for (size_t y = 1; in_order && y < parts.size(); ++y) in_order = parts[y]->part_lo == parts[y - 1]->part_lo + parts[y - 1]->n_order;
+            if (!in_order || parts.back()->part_lo + parts.back()->n_order != (int64_t)part_ratings.size()) {
+                err = "build_schedule: internal error, the device-packed chunks do not tile their rating list";
+                return -1;
+            }
+            p_ro.resize(parts.size());
+            p_eo.resize(parts.size());
+            p_oo.resize(parts.size());
+            p_cptr.assign(parts.size() * (size_t)WW + 1, 0);
             std::atomic<size_t> nx{0};
             auto fill = [&]() {
                 for (;;) {
-                    const size_t y0 = nx.fetch_add(64);
-                    if (y0 >= p_desc.size()) break;
-                    for (size_t y = y0; y < std::min(p_desc.size(), y0 + 64); ++y) {
-                        const CellOut& o = *by_desc[(size_t)p_desc[y]];
-                        const int64_t base = p_at[y];
-                        std::memcpy(&p_idx[(size_t)base], o.a().part_idx.data(), o.a().part_idx.size() * sizeof(uint32_t));
+                    const size_t y0 = nx.fetch_add(256);
+                    if (y0 >= parts.size()) break;
+                    for (size_t y = y0; y < std::min(parts.size(), y0 + 256); ++y) {
+                        const CellOut& o = *parts[y];
+                        const CellDesc& d = out.cells[(size_t)o.desc];
+                        const int64_t c = part_cell[y];
+                        p_ro[y] = d.row_off;
+                        p_eo[y] = d.ent_off;
+                        p_oo[y] = ord_off[(size_t)c] + (o.part_lo - co[(size_t)c].part_lo);
+                        const uint16_t* sb = &part_sbs[(size_t)o.part_lo];
+                        const size_t m = (size_t)o.n_order;
                         size_t at = 0;
                         for (int sbi = 0; sbi < WW; ++sbi) {
-                            p_cptr[y * (size_t)WW + (size_t)sbi] = base + (int64_t)at;
-                            while (at < o.a().part_sb.size() && o.a().part_sb[at] == (uint16_t)sbi) ++at;
+                            p_cptr[y * (size_t)WW + (size_t)sbi] = o.part_lo + (int64_t)at;
+                            while (at < m && sb[at] == (uint16_t)sbi) ++at;
                         }
                     }
                 }
             };
             std::vector<std::thread> th;
-            for (int t = 1; t < nthreads; ++t) th.emplace_back(fill);
+            for (int t = 1; t < (parts.size() >= 4096 ? nthreads : 1); ++t) th.emplace_back(fill);
             fill();
             for (auto& t : th) t.join();
-            p_cptr[p_ro.size() * (size_t)WW] = p_total;
-        }
-        p_oo.assign(p_ro.size(), 0);
-        for (int64_t x = 0; x < ncell; ++x) {
-            const int64_t rd = x / B, b = x % B;
-            ord_off[(size_t)(b * B + (b + rd) % B)] = out.cell_ptr[(size_t)x];
+            p_cptr[parts.size() * (size_t)WW] = (int64_t)part_ratings.size();
         }
         for (const int64_t c : walk_cells) {
             int64_t at = ord_off[(size_t)c];
             auto piece = [&](const CellOut& o) {
-                if (o.dev_part) {
-                    p_oo[(size_t)part_of_desc[(size_t)o.desc]] = at;
-                } else if (!o.dev && !o.a().order.empty()) {
+                if (!o.dev && !o.dev_part && !o.a().order.empty()) {
                     mp.seg_order.push_back({(uint64_t)at, (uint64_t)mp.order.size(), (uint64_t)o.a().order.size()});
                     mp.order.insert(mp.order.end(), o.a().order.begin(), o.a().order.end());
                 }
@@ -1630,8 +1702,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             }
             lap("  mixed: lists of the chunks");
             if (ext->pack_emit_parts(prm.ingest->ctx, row_off.data(), ent_off.data(), ord_off.data(), tot_rows, tot_steps,
-                                     (int64_t)p_ro.size(), p_idx.data(), (int64_t)p_idx.size(), p_cptr.data(), p_ro.data(), p_eo.data(),
-                                     p_oo.data(), &out.dev.buf) != 0) {
+                                     (int64_t)p_ro.size(), part_ratings.data(), (int64_t)part_ratings.size(), p_cptr.data(), p_ro.data(),
+                                     p_eo.data(), p_oo.data(), &out.dev.buf) != 0) {
                 err = "build_schedule: the device packer's EMIT pass (cells and chunks) failed";
                 return -1;
             }
