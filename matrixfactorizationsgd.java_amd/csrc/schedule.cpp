@@ -87,6 +87,34 @@ int lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>&
                deg[(size_t)idx[(size_t)giants]] >= std::max(mean, giant_min))
             ++giants;
     }
+    // Every row goes to the bin with the smallest (load, bin).  [r3] The smallest load never decreases and no load is
+    // ever more than the largest count above it, so the bins live in a ring of buckets indexed by load: a bucket is
+    // appended to while it lies ahead, sorted by bin once when the front reaches it, and then consumed from its start
+    // (nothing can be added to the front bucket: every count is at least 1).  The same assignment as the heap below,
+    // which stays for small inputs and absurd counts: 1.23 s -> see DESIGN section 8 at 10 M users and 14 848 bins.
+    const int64_t dmax_all = idx.empty() ? 0 : deg[(size_t)idx[0]];
+    if (idx.size() >= 4096 && nbins >= 16 && dmax_all < ((int64_t)1 << 22) && !std::getenv("MFSGD_LPT_HEAP")) {
+        const int64_t ring = dmax_all + 1;
+        std::vector<std::vector<int32_t>> bucket((size_t)ring);
+        for (int32_t b = 0; b < nbins; ++b)
+            if (!(b >= stride && stride > 0 && b % stride < giants)) bucket[0].push_back(b);  // ascending: sorted
+        int64_t load = 0;  // the front bucket's load
+        size_t pos = 0;    // consumed so far of the front bucket
+        for (int32_t x : idx) {
+            std::vector<int32_t>* front = &bucket[(size_t)(load % ring)];
+            while (pos == front->size()) {
+                front->clear();
+                ++load;
+                pos = 0;
+                front = &bucket[(size_t)(load % ring)];
+                if (front->size() > 1) std::sort(front->begin(), front->end());
+            }
+            const int32_t b = (*front)[pos++];
+            bin[(size_t)x] = b;
+            bucket[(size_t)((load + deg[(size_t)x]) % ring)].push_back(b);
+        }
+        return giants;
+    }
     // (load, bin): smallest load, then smallest bin.  A binary min-heap whose top is replaced in place -- one
     // sift-down per row instead of priority_queue's pop + push; the order of equal keys cannot matter, the keys
     // (load, bin) are distinct

@@ -129,6 +129,35 @@ def test_schedule_is_deterministic(mf):
     np.testing.assert_array_equal(orders[0], orders[1])
 
 
+def test_lpt_bucket_ring_and_heap_give_the_same_assignment(mf, monkeypatch):
+    """[r3] lpt_assign walks the bins through a ring of buckets indexed by load (large inputs) or a binary heap (small
+    ones, MFSGD_LPT_HEAP=1): the same greedy, so the same schedule, word for word -- skewed counts, many equal counts,
+    an item with a tile of its own, auto and explicit geometry."""
+    rng = np.random.default_rng(11)
+    U, I = 30000, 9000
+    n = 400000
+    u = rng.integers(0, U, n)
+    i = np.minimum((rng.pareto(1.1, n) * 40).astype(np.int64), I - 1)  # heavy head, long tail of equal small counts
+    key = np.unique(u.astype(np.int64) * I + i)
+    u, i = (key // I).astype(np.int32), (key % I).astype(np.int32)
+    r = (rng.random(key.size) * 4 + 1).astype(np.float32)
+    for kw in ({}, {"blocks": 24, "waves": 4}, {"blocks": 8, "waves": 2}):
+        got = []
+        for heap in (False, True):
+            if heap:
+                monkeypatch.setenv("MFSGD_LPT_HEAP", "1")
+            else:
+                monkeypatch.delenv("MFSGD_LPT_HEAP", raising=False)
+            with mf.MatrixFactorizationSGD(U, I, 64, LR, LAM, 3, **kw) as m:
+                m.set_ratings(u, i, r)
+                got.append((m.order(), m.debug_schedule(), m.schedule_info()))
+        np.testing.assert_array_equal(got[0][0][0], got[1][0][0])
+        np.testing.assert_array_equal(got[0][0][1], got[1][0][1])
+        for a, b in zip(got[0][1], got[1][1]):
+            np.testing.assert_array_equal(a, b)
+        assert got[0][2]["blocks"] * got[0][2]["waves"] >= 16  # (the ring is taken from 16 bins and 4 096 rows up)
+
+
 def test_partitioned_schedules_cover_everything(mf, oracle):
     w = mf.synth.workload("cfg1_ml100k", scale=0.3)
     G = 3
