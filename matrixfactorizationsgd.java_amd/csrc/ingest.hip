@@ -340,7 +340,8 @@ int pack_count_cb(void* vctx, const PackRequest& q, std::vector<PackCellInfo>& i
     // image (160 KiB) cannot hold more than 10240 16-byte units of rows anyway.  Most cells touch far fewer, and
     // the kernel's occupancy hangs on this number (its per-wave state arrays), so a first launch provides for
     // 512 and only a set with fuller cells pays for a second launch with the full bound.
-    const int rows_full = std::max(8, (int)std::min<int64_t>(std::min<int64_t>(2 * (int64_t)a.max_m, (int64_t)mu + mi), 32767 / std::max(1, q.L)));
+    int rows_full = std::max(8, (int)std::min<int64_t>(std::min<int64_t>(2 * (int64_t)a.max_m, (int64_t)mu + mi), 32767 / std::max(1, q.L)));
+    if (q.fit_rows > 0) rows_full = std::max(8, std::min(rows_full, q.fit_rows));  // (more rows than fit: cut anyway)
     a.max_rows = std::min(rows_full, 512);
     a.B = q.B;
     a.W = q.W;

@@ -45,6 +45,10 @@ struct PackRequest {
     float lr = 0.f, c = 0.f;
     bool solo_ok = false;
     int64_t max_cell_nnz = 0;       // from bptr
+    // the most rows a chunk of the training kernel's LDS image can hold (0: not said).  A cell with more is cut whatever
+    // it packs into, so the packing kernel need not provide for it: it reports such a cell as too large (status 2, row
+    // counts valid) and keeps the smaller per-wave arrays -- and the better occupancy -- for everything else.
+    int fit_rows = 0;
     // [r3] host, per cell, or null: where the cell's ratings start in the canonical order (it follows from the bucket
     // starts alone).  With it the COUNT pass also WRITES what it packs -- rows and entries into scratch arrays at
     // worst-case offsets, the order at its final place -- and the emit calls below only move the cells that are kept to

@@ -645,6 +645,12 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             q.lr = hy.lr;
             q.c = hy.c;
             q.solo_ok = solo_ok;
+            {
+                // rows of the largest chunk the training kernel can hold beside the smallest schedule
+                int64_t fit = (avail - 2 * min_sched) / geo.rowbytes - 2 * G;
+                while (fit > 0 && !(addressable((int)fit) && rows_bytes_for(geo, (int)fit) + 2 * min_sched <= avail)) --fit;
+                q.fit_rows = (int)std::max<int64_t>(fit, 0);
+            }
             for (int64_t cc = 0; cc < ncell; ++cc)
                 q.max_cell_nnz = std::max(q.max_cell_nnz, bptr[(size_t)((cc + 1) * WW)] - bptr[(size_t)(cc * WW)]);
             // canonical order: rounds, then blocks; a cell's ratings are contiguous.  Known from the bucket starts alone,
