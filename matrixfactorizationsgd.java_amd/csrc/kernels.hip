@@ -815,15 +815,25 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         cx.zero_idle_rows();
         // The rows stored at the end of the previous iteration may be gathered again below.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MFSGD_DIAG_SPLIT_PHASE0  // (a build for tools/phase_profile.py that takes phase 0 apart)
+        mark(0);  // phase 0 = zeroing + drain only
+#endif
         if (it1.R < n_rounds) cx.prefetch_schedule(cd1, (int)it1.idx, smem, buf ^ 1, sched_cap, rows, subs, entries);
         if (work) cx.gather(P, Q, 0, cx.nu);  // own rows: no dependency on other workgroups
         // descriptor used two iterations from now: a scalar load issued here, in front of the wait for the tile,
         // so that it completes in that wait's shadow (behind the tile gather it was exposed -- ~1.4 K cycles --
         // whenever there was no gather to hide it: a tile taken from its mailbox)
         const Item it2 = next_item(it1, cd1);
-        if (it2.R < n_rounds) cd2 = load_desc(cells, it2.idx);
-        mark(0);  // drain of the previous stores + issue of the prefetch and the P gather
         const bool lone = KP >= 64 && (cd.rsv[0] & kCellLoneTile) != 0;  // uniform
+#ifdef MFSGD_DIAG_SPLIT_PHASE0
+        mark(2);  // diagnostic build: the issue of prefetch and gather, booked under "barrier"
+#endif
+        if (it2.R < n_rounds) cd2 = load_desc(cells, it2.idx);
+#ifdef MFSGD_DIAG_SPLIT_PHASE0
+        mark(6);  // diagnostic build: the descriptor load (s_memtime waits for it), booked under "own store"
+#else
+        mark(0);  // drain of the previous stores + issue of the prefetch and the P gather
+#endif
         if (R > 0 && it0.first && lone) {
             // the tile is one row: take it from the tile's mailbox as soon as block b + 1 has posted it
             if (cx.wave_all == 0) {
