@@ -731,6 +731,10 @@ int mfsgd_set_ratings(mfsgd_handle* h, const int32_t* u, const int32_t* i, const
         prm.threads = h->cfg.host_threads;
         prm.solo = !(h->cfg.flags & MFSGD_FLAG_NO_SOLO);
         prm.device_pack = !(h->cfg.flags & MFSGD_FLAG_HOST_PACK);
+        if (const char* e = std::getenv("MFSGD_LDS_BUDGET")) {  // (A/B measurements: e.g. 81408 = two workgroups per CU)
+            const int v = std::atoi(e);
+            if (v >= 16 * 1024 && v <= prm.lds_budget) prm.lds_budget = v;
+        }
         if (G == 1) {
             Part& p = h->parts[0];
             p.q_rows = h->cfg.n_items;
