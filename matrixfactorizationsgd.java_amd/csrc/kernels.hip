@@ -167,6 +167,13 @@ struct Cell {
     int nu, nrows, n_steps;
     bool critical;  // the cell carries a long per-row chain (scheduler flag)
     volatile unsigned* fail_flag = nullptr;  // LDS control word a helper raises when it gives up (persistent kernel)
+    // [r3] Early hand-off of a tile that is ONE row (run_ring's mailboxes): when the cell's last work is a solo run, the
+    // chain wave posts the row from its registers the moment the run ends -- {value, tag} granules at post_at, tag
+    // post_tag -- instead of leaving it to the workgroup behind the helper's stores, the sub-round barriers and an LDS
+    // round trip; it says so in *posted_flag (an LDS control word), and the workgroup does not post again.
+    unsigned long long* post_at = nullptr;
+    unsigned post_tag = 0;
+    volatile unsigned* posted_flag = nullptr;
     unsigned char* lrows;
     uint4* lent;
     uint2* lsub;
@@ -494,6 +501,20 @@ struct Cell {
                     const unsigned rowbase = (unsigned)(uintptr_t)(lptr_t)lr_ + lo;
                     float4 q = lds_ld(lr_, rqa);
                     solo_chain_asm<L>(q, (unsigned)(uintptr_t)(lptr_t)hdr, rowbase, nsolo, lr, c2);
+                    // the run was the cell's last work (its records end where the cell's steps end): hand the row on now
+                    const int units = (nsolo + 2 + G - 1) / G + kSoloPad;
+                    if (post_at != nullptr && (offs & 0xFFFF) + n + nr + units + 2 == n_steps) {
+                        if (lane < L) {  // lane group 0: lane l holds elements 4l .. 4l + 3 of the row
+                            using gu64 = __attribute__((address_space(1))) unsigned long long;
+                            gu64* dst = (gu64*)post_at + lig * 4;
+                            const unsigned long long tag = (unsigned long long)post_tag << 32;
+                            __hip_atomic_store(dst + 0, tag | __builtin_bit_cast(unsigned, q.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(dst + 1, tag | __builtin_bit_cast(unsigned, q.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(dst + 2, tag | __builtin_bit_cast(unsigned, q.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(dst + 3, tag | __builtin_bit_cast(unsigned, q.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        if (lane == 0) *posted_flag = 1u;
+                    }
                 } else if constexpr (TRAIN) {
                     // one wave does everything (kernels without copy waves); every lane group computes the
                     // same step -- the chain is sequential -- and they all store the same bits
@@ -664,6 +685,7 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
     Cell<L, W, NH> cx;
     cx.init_thread();
     cx.fail_flag = ctl;
+    cx.posted_flag = ctl + 3;
     // Start-of-launch rendezvous, before anything is touched.  It does two jobs with one device-side
     // barrier (sense reversing: abort_word[-4] counts arrivals, abort_word[-3] is the generation):
     //  * the hand-off flags are reset HERE, by their owners (block b's flag by the workgroup that runs
@@ -813,6 +835,7 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
         const bool work = cx.nrows != 0;  // uniform over the workgroup
         const bool last = cd.next == 0;   // last chunk of its cell: the tile is handed on after it
         cx.zero_idle_rows();
+        if (cx.tid == 0) ctl[3] = 0u;  // "the chain wave has posted the tile's row" (read behind the barriers below)
         // The rows stored at the end of the previous iteration may be gathered again below.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef MFSGD_DIAG_SPLIT_PHASE0  // (a build for tools/phase_profile.py that takes phase 0 apart)
@@ -886,27 +909,36 @@ __device__ __forceinline__ void run_ring(unsigned char* smem, float* __restrict_
             }
         }
         mark(1);  // waiting for the tile (wave 0)
+        const bool from_mbox = lone && R > 0;  // the tile's row is in LDS already (wave 0 put it there)
+        // (Waiting for the own rows in front of this barrier and dropping the second one for a row that came from its
+        // mailbox -- one barrier less on the hop the epoch waits for -- was measured: 4.00 against 3.97 ms per epoch
+        // on the same box, three runs each; the second barrier stays.)
         wg_barrier();
         mark(2);  // the other waves' arrival
         if (ctl[0] != 0) {  // uniform: some workgroup timed out (or a solo helper of this one gave up)
             if (cx.tid == 0) __hip_atomic_store((gu32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        (void)0;
-        const bool from_mbox = lone && R > 0;  // the row is in LDS already
         if (work && !from_mbox) cx.template gather<true>(P, Q, cx.nu, cx.nrows);  // the tile's q rows, sc1: stored by another CU
         if (work) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows (and the prefetched schedule) have landed
             wg_barrier();
             mark(3);  // tile rows (and own rows, and the next schedule) landed
             double acc = 0.0;
+            if (lone && R + 1 < n_rounds) {
+                cx.post_at = (unsigned long long*)(abort_word + 4) + (size_t)((b + R % B) % B) * KP;  // the tile's mailbox
+                cx.post_tag = tag_hi | (unsigned)(R + 1);
+            } else {
+                cx.post_at = nullptr;
+            }
             cx.template apply<true>(lr, c, acc);  // ends with a workgroup barrier
             mark(4);  // the ratings
             // write-through even when more chunks of this cell follow: item rows that no later
             // chunk touches have to be visible to the next workgroup all the same
             if (lone && R + 1 < n_rounds) {
                 // post the row for block b - 1 (round R + 1); Q gets it from the holder in the last round
-                if (cx.wave_all == 0) {
+                // (unless the chain wave has posted it from its registers already, Cell::post_at)
+                if (cx.wave_all == 0 && ctl[3] == 0u) {
                     const unsigned tile = (unsigned)((b + R % B) % B);
                     const unsigned long long tag = (unsigned long long)(tag_hi | (unsigned)(R + 1)) << 32;
                     gu64* dst = mbox + (size_t)tile * KP + cx.lane;
