@@ -93,7 +93,7 @@ int lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>&
     // (nothing can be added to the front bucket: every count is at least 1).  The same assignment as the heap below,
     // which stays for small inputs and absurd counts: 1.23 s -> see DESIGN section 8 at 10 M users and 14 848 bins.
     const int64_t dmax_all = idx.empty() ? 0 : deg[(size_t)idx[0]];
-    if (idx.size() >= 4096 && nbins >= 16 && dmax_all < ((int64_t)1 << 22) && !std::getenv("MFSGD_LPT_HEAP")) {
+    if (idx.size() >= 4096 && nbins >= 16 && dmax_all < ((int64_t)1 << 20) && !std::getenv("MFSGD_LPT_HEAP")) {  // (ring: 24 B per count)
         const int64_t ring = dmax_all + 1;
         std::vector<std::vector<int32_t>> bucket((size_t)ring);
         for (int32_t b = 0; b < nbins; ++b)
