@@ -91,7 +91,7 @@ int lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>&
     // ever more than the largest count above it, so the bins live in a ring of buckets indexed by load: a bucket is
     // appended to while it lies ahead, sorted by bin once when the front reaches it, and then consumed from its start
     // (nothing can be added to the front bucket: every count is at least 1).  The same assignment as the heap below,
-    // which stays for small inputs and absurd counts: 1.23 s -> see DESIGN section 8 at 10 M users and 14 848 bins.
+    // which stays for small inputs and absurd counts: 1.23 -> 0.49 s at 10 M users and 14 848 bins, 30 -> 9 ms at 480 K.
     const int64_t dmax_all = idx.empty() ? 0 : deg[(size_t)idx[0]];
     if (idx.size() >= 4096 && nbins >= 16 && dmax_all < ((int64_t)1 << 20) && !std::getenv("MFSGD_LPT_HEAP")) {  // (ring: 24 B per count)
         const int64_t ring = dmax_all + 1;
