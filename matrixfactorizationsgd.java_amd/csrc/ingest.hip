@@ -246,12 +246,11 @@ fail:
 }
 
 int fetch_bptr(Ctx* c, int64_t* bptr) {
-    std::vector<long long> hb((size_t)(c->nb + 1));
-    if (hipMemcpy(hb.data(), c->d_bptr, sizeof(long long) * hb.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+    static_assert(sizeof(long long) == sizeof(int64_t), "the bucket starts come down as they are");
+    if (hipMemcpy(bptr, c->d_bptr, sizeof(long long) * (size_t)(c->nb + 1), hipMemcpyDeviceToHost) != hipSuccess) {
         (void)hipGetLastError();
         return -1;
     }
-    for (int64_t b = 0; b <= c->nb; ++b) bptr[b] = (int64_t)hb[(size_t)b];
     return 0;
 }
 
