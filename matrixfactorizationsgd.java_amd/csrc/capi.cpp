@@ -82,6 +82,7 @@ struct mfsgd_handle {
     int n_cu = 0;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;  // diagnostics only (mfsgd_debug_occupy)
+    unsigned* occupy_started = nullptr; // ... pinned host word its workgroups count themselves in
     int64_t n_not_resident = 0;         // persistent launches that gave up at the residency check
     // identity of the rating set the schedules were built from: its length and a 128-bit hash of every
     // byte of u, i and r -- a repeated mfsgd_set_ratings with the same triples keeps the schedules
@@ -634,6 +635,8 @@ void mfsgd_destroy(mfsgd_handle* h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->side_stream) {
         (void)hipStreamSynchronize(h->side_stream);
+        if (h->occupy_started) (void)hipHostFree(h->occupy_started);
+        h->occupy_started = nullptr;
         (void)hipStreamDestroy(h->side_stream);
     }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1215,8 +1218,19 @@ int mfsgd_debug_occupy(mfsgd_handle* h, int32_t milliseconds) {
     if (!h->side_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     // one workgroup on all but four CUs, each with (nearly) the whole LDS: nothing that needs LDS fits beside
     // it, and a persistent launch of more than a handful of workgroups finds only SOME of them resident
-    HIPCHK(h, launch_occupy(std::max(1, h->n_cu - 4), 160 * 1024 - 1024, (unsigned long long)milliseconds * 100000ull,
-                            h->side_stream));
+    // ... once they are ON the CUs: a launch on another stream is not ordered against what the caller launches
+    // next, and a training launch that overtook this kernel met an empty chip (the not-resident test failed once in
+    // five full runs that way).  The workgroups count themselves in a pinned host word; this call returns when all
+    // have started (or after 0.2 s: a chip too busy to take them is occupied enough).
+    if (!h->occupy_started) HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->occupy_started), sizeof(unsigned), hipHostMallocDefault));
+    HIPCHK(h, hipStreamSynchronize(h->side_stream));  // (an earlier occupation has ended: the word is ours)
+    *h->occupy_started = 0u;
+    const int wgs = std::max(1, h->n_cu - 4);
+    HIPCHK(h, launch_occupy(wgs, 160 * 1024 - 1024, (unsigned long long)milliseconds * 100000ull, h->occupy_started, h->side_stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    while (__atomic_load_n(h->occupy_started, __ATOMIC_ACQUIRE) < (unsigned)wgs &&
+           std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200))
+        std::this_thread::yield();
     return MFSGD_OK;
 }
 

@@ -1243,17 +1243,18 @@ hipError_t launch_init_rows(float* dst, long long rows, int k, int kp, long long
 }
 
 // Diagnostic: workgroups that hold a whole CU's LDS and spin for `ticks` of the 100 MHz clock.
-__global__ void __launch_bounds__(64) occupy_kernel(const unsigned long long ticks) {
+__global__ void __launch_bounds__(64) occupy_kernel(const unsigned long long ticks, unsigned* __restrict__ started) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     smem[threadIdx.x] = 0;
+    if (started && threadIdx.x == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
-hipError_t launch_occupy(int workgroups, int lds_bytes, unsigned long long ticks, hipStream_t st) {
+hipError_t launch_occupy(int workgroups, int lds_bytes, unsigned long long ticks, unsigned* started, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)workgroups), dim3(64), (size_t)lds_bytes, st, ticks);
+    hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)workgroups), dim3(64), (size_t)lds_bytes, st, ticks, started);
     return hipGetLastError();
 }
 

@@ -47,7 +47,8 @@ hipError_t launch_init_rows(float* dst, long long rows, int k, int kp, long long
                             hipStream_t st);
 
 // Diagnostic (tests): `workgroups` one-wave workgroups, each holding lds_bytes of LDS, spin for `ticks` x 10 ns.
-hipError_t launch_occupy(int workgroups, int lds_bytes, unsigned long long ticks, hipStream_t st);
+// `started` (device-accessible host memory, or null): every workgroup adds one to it as it starts
+hipError_t launch_occupy(int workgroups, int lds_bytes, unsigned long long ticks, unsigned* started, hipStream_t st);
 
 // recommend.hip: fused score + select (one workgroup per user, nothing but the winners goes to memory) for
 // the (n_items, topn) recommend_is_fused() accepts ...
