@@ -47,7 +47,7 @@ copy)
         cp "$(ls -t $d/write/*/*counter_collection.csv | head -1)" profiles/${TAG}_${k}_pmc_WRITE_SIZE.csv
     done
     for f in $OUT/bench_*.json $OUT/phase_profile_*.log $OUT/ubench3.log; do cp $f profiles/${TAG}_$(basename $f); done
-    for f in $OUT/sched_trace_*.log; do [ -f $f ] && grep -v amdgpu.ids $f > profiles/${TAG}_$(basename $f); done
+    for f in $OUT/sched_trace_*.log; do if [ -f $f ]; then grep -v amdgpu.ids $f > profiles/${TAG}_$(basename $f); fi; done
     ;;
 *) echo "usage: $0 prof|bench|sched|copy TAG"; exit 2 ;;
 esac
