@@ -246,3 +246,21 @@ def test_dsgd_rehearsal_transport_is_not_in_the_product_library(mf, monkeypatch,
                        stderr=subprocess.STDOUT, text=True)
     assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stdout
 
+
+
+def test_every_environment_variable_the_library_reads_is_documented():
+    """INTEGRATION.md's table of environment variables covers every getenv("MFSGD_...") in the library's sources
+    (they are A/B and test switches: none is needed in production, all must be findable)."""
+    import glob
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    read = set()
+    for f in glob.glob(os.path.join(root, "matrixfactorizationsgd.java_amd", "csrc", "*")):
+        if f.endswith((".cpp", ".hip", ".hpp")):
+            read |= set(re.findall(r'getenv\("(MFSGD_[A-Z0-9_]+)"\)', open(f).read()))
+    assert len(read) >= 10, read
+    missing = sorted(v for v in read if v not in doc)
+    assert not missing, missing
