@@ -211,7 +211,15 @@ int ensure_part_on_device(mfsgd_handle* h, Part& p) {
     if (p.on_device) return MFSGD_OK;
     int rc;
     if ((rc = upload(h, p.d_cells, p.sched.cells))) return rc;
-    if ((rc = upload(h, p.d_subs, p.sched.subs))) return rc;
+    if (p.sched.device_packed && p.sched.dev.buf.subs) {
+        // (the device assembled the sub-cell tables too)
+        p.d_subs.release();
+        p.d_subs.p = p.sched.dev.buf.subs;
+        p.d_subs.bytes = (size_t)p.sched.dev.buf.n_subs * sizeof(SubDesc);
+        p.sched.dev.buf.subs = nullptr;
+    } else if ((rc = upload(h, p.d_subs, p.sched.subs))) {
+        return rc;
+    }
     if (p.sched.device_packed) {
         // the device packer left rows and entries where they are needed
         p.d_rows.release();
@@ -463,6 +471,14 @@ int host_copies(const mfsgd_handle* h, const Part& cp, bool want_order, bool wan
             s.order.resize_uninit((size_t)s.nnz);
             if (s.dev_ops->download(d, nullptr, 0, nullptr, 0, s.order.data(), s.nnz) != 0)
                 return fail(h, MFSGD_ERR_HIP, "could not copy the canonical order from the device");
+        }
+        if (want_arrays && s.subs.empty() && s.n_sub_recs > 0 && s.dev_ops->download_raw) {
+            const void* dsubs = p.on_device ? p.d_subs.p : s.dev.buf.subs;
+            if (dsubs) {
+                s.subs.resize((size_t)s.n_sub_recs);
+                if (s.dev_ops->download_raw(dsubs, s.subs.data(), s.subs.size() * sizeof(SubDesc)) != 0)
+                    return fail(h, MFSGD_ERR_HIP, "could not copy the sub-cell tables from the device");
+            }
         }
         if (want_arrays && s.entries.empty() && s.n_entry_recs > 0) {
             s.rows.resize_uninit((size_t)s.n_rows_words);
@@ -1155,7 +1171,7 @@ int mfsgd_debug_schedule_sizes(const mfsgd_handle* h, int32_t part, int64_t* n_c
     const Schedule& s = h->parts[(size_t)part].sched;
     *n_cells = (int64_t)s.cells.size();
     *n_rows = s.n_rows_words;
-    *n_subs = (int64_t)s.subs.size();
+    *n_subs = s.subs.empty() ? s.n_sub_recs : (int64_t)s.subs.size();
     *n_entries = s.n_entry_recs;
     return MFSGD_OK;
 }
@@ -1165,7 +1181,7 @@ int mfsgd_debug_get_schedule(const mfsgd_handle* h, int32_t part, uint32_t* cell
     if (!h) return MFSGD_ERR_INVALID_ARG;
     if (!h->have_ratings) return fail(h, MFSGD_ERR_STATE, "debug_get_schedule: no ratings");
     if (part < 0 || part >= h->n_parts) return fail(h, MFSGD_ERR_INVALID_ARG, "debug_get_schedule: bad partition");
-    if (rows || entries) {
+    if (rows || entries || subs) {
         const int rc = host_copies(h, h->parts[(size_t)part], false, true);
         if (rc) return rc;
     }

@@ -436,8 +436,12 @@ int pack_count_cb(void* vctx, const PackRequest& q, std::vector<PackCellInfo>& i
     }
     reserve_huge(info, (size_t)n_cells);
     info.resize((size_t)n_cells);
-    reserve_huge(subs, (size_t)(n_cells * WW));
-    subs.resize((size_t)(n_cells * WW));
+    if (q.want_subs) {
+        reserve_huge(subs, (size_t)(n_cells * WW));
+        subs.resize((size_t)(n_cells * WW));
+    } else {
+        subs.clear();
+    }
     for (;;) {
         ING_CHK(launch_pack(a, n_cells, (hipStream_t)0));
         ING_CHK(hipMemcpy(info.data(), c->d_info, sizeof(PackCellInfo) * (size_t)n_cells, hipMemcpyDeviceToHost));
@@ -446,7 +450,7 @@ int pack_count_cb(void* vctx, const PackRequest& q, std::vector<PackCellInfo>& i
         if (!more_rows || a.max_rows >= rows_full) break;
         a.max_rows = rows_full;
     }
-    ING_CHK(hipMemcpy(subs.data(), c->d_subs, sizeof(SubDesc) * (size_t)(n_cells * WW), hipMemcpyDeviceToHost));
+    if (q.want_subs) ING_CHK(hipMemcpy(subs.data(), c->d_subs, sizeof(SubDesc) * (size_t)(n_cells * WW), hipMemcpyDeviceToHost));
     c->args = a;
     c->n_cells = n_cells;
     c->rows_full = rows_full;
@@ -512,7 +516,7 @@ int pack_count_parts_cb(void* vctx, int64_t n_parts, const uint32_t* sorted, int
     int rc = -1;
     ING_CHK(launch_pack(a, n_parts, (hipStream_t)0));
     ING_CHK(hipMemcpy(info, pl.d_info, sizeof(PackCellInfo) * (size_t)n_parts, hipMemcpyDeviceToHost));
-    ING_CHK(hipMemcpy(subs, pl.d_subs, sizeof(SubDesc) * (size_t)(n_parts * WW), hipMemcpyDeviceToHost));
+    if (subs) ING_CHK(hipMemcpy(subs, pl.d_subs, sizeof(SubDesc) * (size_t)(n_parts * WW), hipMemcpyDeviceToHost));
     rc = 0;
 fail:
     pl.release();
@@ -525,12 +529,24 @@ struct PartsToEmit {
     const int64_t* cptr = nullptr;
     const uint32_t *row_off = nullptr, *ent_off = nullptr;
     const int64_t* ord_off = nullptr;
+    const int64_t* desc = nullptr;  // the chunk descriptor of every part (final sub-cell table)
 };
 
+// fin[desc[y] * WW + x] = src[y * WW + x]: the parts' sub-cell tables to their chunk descriptors
+__global__ void __launch_bounds__(256) table_scatter_kernel(SubDesc* __restrict__ fin, const SubDesc* __restrict__ src,
+                                                            const long long* __restrict__ desc, const long long n_parts, const int WW) {
+    const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (x >= n_parts * WW) return;
+    fin[desc[x / WW] * WW + x % WW] = src[x];
+}
+
 int emit_common(Ctx* c, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
-                int64_t n_steps, const MixedPieces* host, DevicePacked* out, const PartsToEmit* parts = nullptr) {
+                int64_t n_steps, const MixedPieces* host, DevicePacked* out, const PartsToEmit* parts = nullptr,
+                int64_t n_descs = 0) {
     if (!c->d_info || !out) return -1;
     PackArgs a = c->args;
+    SubDesc* d_fin = nullptr;  // the final sub-cell table (n_descs > 0)
+    long long* d_pdesc = nullptr;
     uint32_t *d_ro = nullptr, *d_eo = nullptr, *d_rows = nullptr;
     long long *d_oo = nullptr, *d_order = nullptr;
     Entry* d_ent = nullptr;
@@ -563,6 +579,15 @@ int emit_common(Ctx* c, const uint32_t* row_off, const uint32_t* ent_off, const 
     a.rows = d_rows;
     a.entries = d_ent;
     a.order = d_order;
+    if (n_descs > 0) {
+        // the final sub-cell table: the cells' tables as the COUNT pass left them (a cell that is cut gets its first
+        // chunk's below), zeros for the descriptors nothing is written to and for the two padding records
+        const size_t WWs = (size_t)a.W * a.W;
+        if (n_descs < c->n_cells) goto fail;
+        ING_CHK(hipMalloc(&d_fin, sizeof(SubDesc) * ((size_t)n_descs * WWs + 2)));
+        ING_CHK(hipMemsetAsync(d_fin + (size_t)c->n_cells * WWs, 0, sizeof(SubDesc) * ((size_t)(n_descs - c->n_cells) * WWs + 2), (hipStream_t)0));
+        ING_CHK(hipMemcpyAsync(d_fin, c->d_subs, sizeof(SubDesc) * (size_t)c->n_cells * WWs, hipMemcpyDeviceToDevice, (hipStream_t)0));
+    }
     if (one_pass) {
         a.emit = 2;
         ING_CHK(launch_compact(a, c->n_cells, c->d_srows, c->d_sent, (hipStream_t)0));
@@ -592,7 +617,19 @@ int emit_common(Ctx* c, const uint32_t* row_off, const uint32_t* ent_off, const 
             pa.rows = d_rows;
             pa.entries = d_ent;
             pa.order = d_order;
-            ok = launch_pack(pa, parts->n_parts, (hipStream_t)0) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+            ok = launch_pack(pa, parts->n_parts, (hipStream_t)0) == hipSuccess;
+            if (ok && d_fin) {
+                // (the EMIT pass does not touch the table the COUNT pass of the same list left in pl.d_subs)
+                ok = parts->desc != nullptr && hipMalloc(&d_pdesc, 8 * np) == hipSuccess &&
+                     hipMemcpy(d_pdesc, parts->desc, 8 * np, hipMemcpyHostToDevice) == hipSuccess;
+                if (ok) {
+                    const long long tot = (long long)np * a.W * a.W;
+                    hipLaunchKernelGGL(table_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)0, d_fin, pl.d_subs,
+                                       d_pdesc, (long long)np, a.W * a.W);
+                    ok = hipGetLastError() == hipSuccess;
+                }
+            }
+            ok = ok && hipDeviceSynchronize() == hipSuccess;
         }
         if (p_ro) (void)hipFree(p_ro);
         if (p_eo) (void)hipFree(p_eo);
@@ -621,9 +658,12 @@ int emit_common(Ctx* c, const uint32_t* row_off, const uint32_t* ent_off, const 
     (void)hipFree(d_ro); (void)hipFree(d_eo); (void)hipFree(d_oo);
     for (void* p : staged)
         if (p) (void)hipFree(p);
+    if (d_pdesc) (void)hipFree(d_pdesc);
     out->rows = d_rows;
     out->entries = d_ent;
     out->order = d_order;
+    out->subs = d_fin;
+    out->n_subs = d_fin ? n_descs * (int64_t)a.W * a.W + 2 : 0;
     out->release = release_cb;
     drop_pack_state(c);
     return 0;
@@ -634,14 +674,16 @@ fail:
     if (d_rows) (void)hipFree(d_rows);
     if (d_ent) (void)hipFree(d_ent);
     if (d_order) (void)hipFree(d_order);
+    if (d_fin) (void)hipFree(d_fin);
+    if (d_pdesc) (void)hipFree(d_pdesc);
     for (void* p : staged)
         if (p) (void)hipFree(p);
     return -1;
 }
 
 int pack_emit_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
-                 int64_t n_steps, DevicePacked* out) {
-    return emit_common(static_cast<Ctx*>(vctx), row_off, ent_off, ord_off, n_rows, n_steps, nullptr, out);
+                 int64_t n_steps, int64_t n_descs, DevicePacked* out) {
+    return emit_common(static_cast<Ctx*>(vctx), row_off, ent_off, ord_off, n_rows, n_steps, nullptr, out, nullptr, n_descs);
 }
 
 int pack_emit_mixed_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
@@ -651,8 +693,10 @@ int pack_emit_mixed_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_
 
 int pack_emit_parts_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
                        int64_t n_steps, int64_t n_parts, const uint32_t* sorted, int64_t n_sorted, const int64_t* cptr,
-                       const uint32_t* p_row_off, const uint32_t* p_ent_off, const int64_t* p_ord_off, DevicePacked* out) {
+                       const uint32_t* p_row_off, const uint32_t* p_ent_off, const int64_t* p_ord_off, int64_t n_descs,
+                       const int64_t* p_desc, DevicePacked* out) {
     PartsToEmit pe;
+    pe.desc = p_desc;
     pe.n_parts = n_parts;
     pe.n_sorted = n_sorted;
     pe.sorted = sorted;
@@ -660,7 +704,7 @@ int pack_emit_parts_cb(void* vctx, const uint32_t* row_off, const uint32_t* ent_
     pe.row_off = p_row_off;
     pe.ent_off = p_ent_off;
     pe.ord_off = p_ord_off;
-    return emit_common(static_cast<Ctx*>(vctx), row_off, ent_off, ord_off, n_rows, n_steps, nullptr, out, &pe);
+    return emit_common(static_cast<Ctx*>(vctx), row_off, ent_off, ord_off, n_rows, n_steps, nullptr, out, &pe, n_descs);
 }
 
 int download_cb(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* entries, int64_t n_entries, int64_t* order,
@@ -673,8 +717,17 @@ int download_cb(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* en
     return 0;
 }
 
+int download_raw_cb(const void* dev, void* host, size_t bytes) {
+    if (bytes == 0) return 0;
+    if (!dev || !host || hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return 0;
+}
+
 const DeviceIngestExt kExt = {bucket_dev_cb, fetch_sorted_cb, fetch_sorted32_cb, fetch_sorted_ranges_cb, pack_count_cb, pack_emit_cb, pack_emit_mixed_cb,
-                              pack_count_parts_cb, pack_emit_parts_cb, download_cb};
+                              pack_count_parts_cb, pack_emit_parts_cb, download_cb, download_raw_cb};
 
 }  // namespace
 

@@ -49,6 +49,7 @@ struct PackRequest {
     // it packs into, so the packing kernel need not provide for it: it reports such a cell as too large (status 2, row
     // counts valid) and keeps the smaller per-wave arrays -- and the better occupancy -- for everything else.
     int fit_rows = 0;
+    bool want_subs = true;  // false: the per-cell sub-cell tables stay on the device (the caller will ask the emit call for the final table)
     // [r3] host, per cell, or null: where the cell's ratings start in the canonical order (it follows from the bucket
     // starts alone).  With it the COUNT pass also WRITES what it packs -- rows and entries into scratch arrays at
     // worst-case offsets, the order at its final place -- and the emit calls below only move the cells that are kept to
@@ -60,6 +61,11 @@ struct DevicePacked {
     void* rows = nullptr;     // uint32 x n_rows (+4 padding words)
     void* entries = nullptr;  // Entry x n_entries
     void* order = nullptr;    // int64 x n
+    // [r3] the sub-cell tables of all chunk descriptors (n_subs SubDesc records, the two padding records included), when
+    // the emit call was asked for them (n_descs > 0): the device wrote them and the training kernel reads them, so
+    // they need not come to the host and go back
+    void* subs = nullptr;
+    int64_t n_subs = 0;
     void (*release)(void*) = nullptr;
 };
 
@@ -89,8 +95,9 @@ struct DeviceIngestExt {
     // handles (nothing produced), -1 = a HIP call failed
     int (*pack_count)(void* ctx, const PackRequest& req, std::vector<PackCellInfo>& info, std::vector<SubDesc>& subs) = nullptr;
     // EMIT pass at the offsets the caller derived from the COUNT pass (per cell, B*B entries each)
+    // n_descs > 0: also leave the final sub-cell table (n_descs * W*W + 2 records: the cells' tables as counted) in out->subs
     int (*pack_emit)(void* ctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
-                     int64_t n_steps, DevicePacked* out) = nullptr;
+                     int64_t n_steps, int64_t n_descs, DevicePacked* out) = nullptr;
     // EMIT for the cells whose row_off is not 0xFFFFFFFF, then the host-packed pieces scattered to their places
     int (*pack_emit_mixed)(void* ctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
                            int64_t n_steps, const MixedPieces& host, DevicePacked* out) = nullptr;
@@ -105,10 +112,14 @@ struct DeviceIngestExt {
     // that were cut), each at the offsets the caller gives (p_*: per part), into ONE set of arrays
     int (*pack_emit_parts)(void* ctx, const uint32_t* row_off, const uint32_t* ent_off, const int64_t* ord_off, int64_t n_rows,
                            int64_t n_steps, int64_t n_parts, const uint32_t* sorted, int64_t n_sorted, const int64_t* cptr,
-                           const uint32_t* p_row_off, const uint32_t* p_ent_off, const int64_t* p_ord_off, DevicePacked* out) = nullptr;
+                           const uint32_t* p_row_off, const uint32_t* p_ent_off, const int64_t* p_ord_off,
+                           int64_t n_descs, const int64_t* p_desc, DevicePacked* out) = nullptr;
+    // (n_descs > 0 with p_desc = the chunk descriptor of every part: out->subs = the cells' tables, the parts' tables at
+    // their descriptors, zeros elsewhere)
     // device -> host copies of what emit() produced (debug / get_order); any pointer may be null
     int (*download)(const DevicePacked& d, uint32_t* rows, int64_t n_rows, Entry* entries, int64_t n_entries, int64_t* order,
                     int64_t n) = nullptr;
+    int (*download_raw)(const void* dev, void* host, size_t bytes) = nullptr;  // (the sub-cell tables, for the debug getter)
 };
 
 // Implemented in ingest.hip.  `device` must already be usable (capi checks).

@@ -625,6 +625,13 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     std::vector<PackCellInfo> info;  // per cell, from the device's COUNT pass (kept for the mixed mode)
     std::vector<SubDesc> dsubs;
     bool have_info = false;
+    // [r3] The sub-cell tables (W*W records per chunk descriptor) are written by the device's packer and read by the
+    // training kernel: when the device packs the chunks of cut cells as well, every table is its, and the final array
+    // is assembled THERE (emit: the cells' tables, the chunks' scattered to their descriptors) instead of coming down
+    // with the COUNT results, through place() and up again with the schedule -- 75 MB three times at the Netflix
+    // shape, 1.76 GB three times at 1 B ratings.  Schedule::subs stays empty; the debug getter fetches a copy.
+    const bool dev_tables = ext && ext->download_raw && ext->pack_count_parts && ext->pack_emit_parts && ext->fetch_sorted_ranges &&
+                            !std::getenv("MFSGD_HOST_CHUNKS") && !std::getenv("MFSGD_HOST_TABLES");
     if (sorted_on_device) {
         const char* why = "";
         const int rc = [&]() -> int {
@@ -645,6 +652,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             q.lr = hy.lr;
             q.c = hy.c;
             q.solo_ok = solo_ok;
+            q.want_subs = !dev_tables;  // (the sub-cell tables stay on the device then: emit leaves the final one there)
             {
                 // rows of the largest chunk the training kernel can hold beside the smallest schedule
                 int64_t fit = (avail - 2 * min_sched) / geo.rowbytes - 2 * G;
@@ -710,8 +718,11 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             sch.W = W;
             sch.nnz = n;
             sch.cells.resize((size_t)ncell);
-            sch.subs.assign((size_t)(ncell * WW) + 2, SubDesc{0, 0});
-            std::memcpy(sch.subs.data(), dsubs.data(), sizeof(SubDesc) * (size_t)(ncell * WW));
+            sch.n_sub_recs = ncell * WW + 2;
+            if (!dev_tables) {
+                sch.subs.assign((size_t)(ncell * WW) + 2, SubDesc{0, 0});
+                std::memcpy(sch.subs.data(), dsubs.data(), sizeof(SubDesc) * (size_t)(ncell * WW));
+            }
             for (int64_t cc = 0; cc < ncell; ++cc) {
                 const PackCellInfo& ci = info[(size_t)cc];
                 CellDesc d{};
@@ -741,7 +752,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             }
             lap("  device pack: offsets");
             prc = ext->pack_emit(prm.ingest->ctx, row_off.data(), ent_off.data(), ord_off.data(), tot_rows, tot_steps,
-                                 &sch.dev.buf);
+                                 dev_tables ? ncell : 0, &sch.dev.buf);
             if (prc != 0) return -1;
             lap("  device pack: emit");
             sch.device_packed = true;
@@ -1258,7 +1269,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             for (size_t x = 0; x < level.size(); ++x)
                 if (level[x].candidate) cand.push_back(x);
             std::vector<PackCellInfo> pinfo(cand.size());
-            std::vector<SubDesc> psubs(cand.size() * (size_t)WW);
+            std::vector<SubDesc> psubs(dev_tables ? 0 : cand.size() * (size_t)WW);  // (device tables: not fetched)
             if (!cand.empty()) {
                 std::vector<int64_t> c_at(cand.size() + 1, 0);
                 for (size_t y = 0; y < cand.size(); ++y) c_at[y + 1] = c_at[y] + (level[cand[y]].hi - level[cand[y]].lo);
@@ -1282,7 +1293,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                 cptr[cand.size() * (size_t)WW] = c_at[cand.size()];
                 t_lists += since(t_lvl);
                 if (ext->pack_count_parts(prm.ingest->ctx, (int64_t)cand.size(), lst.data(), (int64_t)lst.size(), cptr.data(),
-                                          pinfo.data(), psubs.data()) != 0) {
+                                          pinfo.data(), dev_tables ? nullptr : psubs.data()) != 0) {
                     err = "build_schedule: the device packer's COUNT pass over the chunks failed";
                     return -1;
                 }
@@ -1300,7 +1311,8 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     lf.hi = p.hi;
                     lf.ci = ci;
                     lf.tab = (int64_t)(part_subs.size() / (size_t)WW);
-                    part_subs.insert(part_subs.end(), psubs.begin() + (long)(y * (size_t)WW), psubs.begin() + (long)((y + 1) * (size_t)WW));
+                    if (!dev_tables)
+                        part_subs.insert(part_subs.end(), psubs.begin() + (long)(y * (size_t)WW), psubs.begin() + (long)((y + 1) * (size_t)WW));
                     leaves.push_back(lf);
                     is_leaf[cand[y]] = 1;
                 }
@@ -1492,9 +1504,14 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
     }
     reserve_huge(out.cells, (size_t)n_descs);
     out.cells.resize((size_t)n_descs);
-    reserve_huge(out.subs, (size_t)(n_descs * WW) + 2);
-    out.subs.resize((size_t)(n_descs * WW) + 2);  // +16 B: the staging DMA reads whole 16-byte units
-    out.subs[(size_t)(n_descs * WW)] = out.subs[(size_t)(n_descs * WW) + 1] = SubDesc{0, 0};
+    // (with the chunks packed on the device the sub-cell tables are assembled there: dev_tables above)
+    const bool host_tables = !(dev_tables && dev_chunks);
+    out.n_sub_recs = n_descs * WW + 2;
+    if (host_tables) {
+        reserve_huge(out.subs, (size_t)(n_descs * WW) + 2);
+        out.subs.resize((size_t)(n_descs * WW) + 2);  // +16 B: the staging DMA reads whole 16-byte units
+        out.subs[(size_t)(n_descs * WW)] = out.subs[(size_t)(n_descs * WW) + 1] = SubDesc{0, 0};
+    }
     std::vector<const CellOut*> by_desc((size_t)n_descs, nullptr);
     int64_t tot_rows = 0, tot_steps = 0;
     int64_t sched_cap = 0, rows_cap = 0;
@@ -1560,7 +1577,9 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                     cdsc.nu = (uint16_t)o.nu;
                     cdsc.ni = (uint16_t)o.ni;
                     o.desc = d;
-                    if (o.dev && o.a().subs.empty() && d < ncell)
+                    if (!host_tables) {
+                        // (the device assembles the table)
+                    } else if (o.dev && o.a().subs.empty() && d < ncell)
                         std::memcpy(&out.subs[(size_t)(d * WW)], &dsubs[(size_t)(d * WW)], sizeof(SubDesc) * (size_t)WW);
                     else if (o.dev_part)
                         std::memcpy(&out.subs[(size_t)(d * WW)], &part_subs[(size_t)(o.part_tab * WW)], sizeof(SubDesc) * (size_t)WW);
@@ -1625,7 +1644,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
         std::vector<uint32_t> row_off((size_t)ncell, 0xFFFFFFFFu), ent_off((size_t)ncell, 0u);
         std::vector<int64_t> ord_off((size_t)ncell, 0);
         std::vector<uint32_t> p_ro, p_eo;
-        std::vector<int64_t> p_cptr, p_oo;
+        std::vector<int64_t> p_cptr, p_oo, p_desc;  // (p_desc: the chunk descriptor of every part, for the device's final sub-cell table)
         // (device cells are first chunks, x < ncell, and most of all descriptors: they are skipped through the compact
         // list of the cells that are anything else)
         for (int64_t x = 0; x < ncell; ++x) {
@@ -1688,6 +1707,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             p_ro.resize(parts.size());
             p_eo.resize(parts.size());
             p_oo.resize(parts.size());
+            p_desc.resize(parts.size());
             p_cptr.assign(parts.size() * (size_t)WW + 1, 0);
             std::atomic<size_t> nx{0};
             auto fill = [&]() {
@@ -1700,6 +1720,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
                         const int64_t c = part_cell[y];
                         p_ro[y] = d.row_off;
                         p_eo[y] = d.ent_off;
+                        p_desc[y] = o.desc;
                         p_oo[y] = ord_off[(size_t)c] + (o.part_lo - co[(size_t)c].part_lo);
                         const uint16_t* sb = &part_sbs[(size_t)o.part_lo];
                         const size_t m = (size_t)o.n_order;
@@ -1729,7 +1750,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             piece(co[(size_t)c]);
             for (const CellOut& o : extra[(size_t)c]) piece(o);
         }
-        if (n_dev_parts > 0) {
+        if (n_dev_parts > 0 || !host_tables) {
             if (!mp.rows.empty() || !mp.entries.empty() || !mp.order.empty()) {
                 err = "build_schedule: internal error, host-packed pieces beside device-packed chunks";
                 return -1;
@@ -1737,7 +1758,7 @@ int build_schedule(const SchedParams& prm, const int32_t* u, const int32_t* i, c
             lap("  mixed: lists of the chunks");
             if (ext->pack_emit_parts(prm.ingest->ctx, row_off.data(), ent_off.data(), ord_off.data(), tot_rows, tot_steps,
                                      (int64_t)p_ro.size(), part_ratings.data(), (int64_t)part_ratings.size(), p_cptr.data(), p_ro.data(),
-                                     p_eo.data(), p_oo.data(), &out.dev.buf) != 0) {
+                                     p_eo.data(), p_oo.data(), host_tables ? 0 : n_descs, p_desc.data(), &out.dev.buf) != 0) {
                 err = "build_schedule: the device packer's EMIT pass (cells and chunks) failed";
                 return -1;
             }

@@ -110,6 +110,7 @@ struct DeviceSchedule {
             buf.release(buf.rows);
             buf.release(buf.entries);
             buf.release(buf.order);
+            buf.release(buf.subs);
         }
         buf = DevicePacked{};
     }
@@ -161,6 +162,7 @@ struct Schedule {
     const DeviceIngestExt* dev_ops = nullptr;  // for the host copies on demand
     int64_t n_rows_words = 0;  // rows[] length incl. the 4 padding words
     int64_t n_entry_recs = 0;  // entries[] length
+    int64_t n_sub_recs = 0;    // subs[] length incl. the 2 padding records (the array itself may live in dev.buf.subs only)
 };
 
 // u/i are row indices into P and into this partition's Q block; orig[j] is the

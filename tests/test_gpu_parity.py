@@ -460,6 +460,21 @@ def test_device_packer_one_pass_and_two_pass_write_the_same_bytes(mf, monkeypatc
             _same_schedule(mf, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"])
 
 
+def test_device_packer_tables_on_the_device_or_through_the_host(mf, monkeypatch):
+    """[r3] The sub-cell tables of a device-packed schedule are assembled on the device (the cells' tables as counted,
+    the chunks' scattered to their descriptors); MFSGD_HOST_TABLES=1 takes them through the host as before.  The debug
+    getter fetches the device's copy: both against the host packer's bytes, with and without cut cells."""
+    cases = (("cfg2_ml20m", 0.02), ("cfg3_netflix", 0.02), ("cfg4_powerlaw", 0.0003))
+    for through_host in (False, True):
+        if through_host:
+            monkeypatch.setenv("MFSGD_HOST_TABLES", "1")
+        else:
+            monkeypatch.delenv("MFSGD_HOST_TABLES", raising=False)
+        for name, scale in cases:
+            w = mf.synth.workload(name, scale)
+            _same_schedule(mf, w["U"], w["I"], w["k"], w["u"], w["i"], w["r"])
+
+
 def test_device_packer_partitioned_handles(mf):
     """n_parts > 1: every partition's schedule through the device packer (the caller-visible rating
     indices go through the `orig` map)."""
