@@ -66,6 +66,7 @@ int lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>&
     // descending by rating count, ties in index order -- a counting sort when the counts are small enough for one
     // (they are: a row has at most as many ratings as there are rows on the other side); [r3] std::stable_sort of
     // 480 K users took 30 of the 65 ms of this function at the Netflix shape, and a second for 10 M users
+    std::vector<int32_t> sdeg;  // the counts in sorted order (beside idx), when they fit: the ring below reads them in sequence
     {
         int64_t dmax = 0;
         for (int32_t x : idx) dmax = std::max(dmax, deg[(size_t)x]);
@@ -74,7 +75,13 @@ int lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>&
             for (int32_t x : idx) start[(size_t)(dmax - deg[(size_t)x]) + 1]++;  // bucket 0 = the largest count
             for (size_t d = 1; d < start.size(); ++d) start[d] += start[d - 1];
             std::vector<int32_t> sorted_idx(idx.size());
-            for (int32_t x : idx) sorted_idx[(size_t)start[(size_t)(dmax - deg[(size_t)x])]++] = x;  // idx ascends: stable
+            sdeg.resize(idx.size());
+            for (int32_t x : idx) {  // idx ascends: stable
+                const int64_t d = deg[(size_t)x];
+                const size_t at = (size_t)start[(size_t)(dmax - d)]++;
+                sorted_idx[at] = x;
+                sdeg[at] = (int32_t)d;
+            }
             idx.swap(sorted_idx);
         } else {
             std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] > deg[(size_t)b]; });
@@ -98,20 +105,30 @@ int lpt_assign(const std::vector<int64_t>& deg, int nbins, std::vector<int32_t>&
         std::vector<std::vector<int32_t>> bucket((size_t)ring);
         for (int32_t b = 0; b < nbins; ++b)
             if (!(b >= stride && stride > 0 && b % stride < giants)) bucket[0].push_back(b);  // ascending: sorted
-        int64_t load = 0;  // the front bucket's load
-        size_t pos = 0;    // consumed so far of the front bucket
-        for (int32_t x : idx) {
-            std::vector<int32_t>* front = &bucket[(size_t)(load % ring)];
+        // (a bucket is filled from the front bucket in ascending bin order; through a long stretch of equal counts --
+        // the tail of any real degree distribution -- it is filled from ONE front bucket and arrives sorted: `mixed`
+        // remembers the buckets that were not, and only those are sorted when the front reaches them)
+        std::vector<uint8_t> mixed((size_t)ring, 0);
+        int64_t at = 0;  // the front bucket: the smallest load modulo the ring (kept by increments: no division per row)
+        size_t pos = 0;  // consumed so far of the front bucket
+        std::vector<int32_t>* front = &bucket[0];
+        for (size_t r = 0; r < idx.size(); ++r) {
+            const int32_t x = idx[r];
             while (pos == front->size()) {
                 front->clear();
-                ++load;
+                mixed[(size_t)at] = 0;
+                if (++at == ring) at = 0;
                 pos = 0;
-                front = &bucket[(size_t)(load % ring)];
-                if (front->size() > 1) std::sort(front->begin(), front->end());
+                front = &bucket[(size_t)at];
+                if (mixed[(size_t)at]) std::sort(front->begin(), front->end());
             }
             const int32_t b = (*front)[pos++];
             bin[(size_t)x] = b;
-            bucket[(size_t)((load + deg[(size_t)x]) % ring)].push_back(b);
+            int64_t to = at + (sdeg.empty() ? deg[(size_t)x] : (int64_t)sdeg[r]);  // 1 <= count <= ring - 1: never the front bucket
+            if (to >= ring) to -= ring;
+            std::vector<int32_t>& dst = bucket[(size_t)to];
+            if (!dst.empty() && dst.back() > b) mixed[(size_t)to] = 1;
+            dst.push_back(b);
         }
         return giants;
     }
